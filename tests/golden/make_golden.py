@@ -1,0 +1,423 @@
+#!/usr/bin/env python3
+"""Record golden trajectories from the UNMODIFIED reference implementation.
+
+Runs only in the build container (needs ``/root/reference``); the GPU box and
+the test-suite read the ``.npz`` files this script writes next to itself.
+
+    python tests/golden/make_golden.py            # regenerate every group
+
+The reference needs numba / aenum / pygame / gymnasium / ray, none of which is
+installed here; ``refshim/`` supplies name-only stand-ins (see its README) so
+that the reference's own ``multigrid/{base,core,utils/obs,envs}`` code executes
+as written.  What is recorded per trajectory:
+
+* the start state (grid ``(W,H,3)``, agent rows, door metadata) - either the
+  reference's own ``reset()`` layout or that layout after a documented harness
+  edit (scattered objects, unlocked doors, carried keys ...), always followed
+  by the reference's own ``gen_obs()``;
+* per step: the actions, the agent order the reference drew
+  (``np_random.random(A).argsort()``, multigrid/base.py:461), everything
+  ``step()`` returned, and the post-step ``grid.state`` / ``agent_states``.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, "/root/reference")
+
+from multigrid.core.constants import Color, Type  # noqa: E402
+from multigrid.core.world_object import (  # noqa: E402
+    Ball, Box, Door, Floor, Goal, Key, Lava, Wall)
+from multigrid.envs import CONFIGURATIONS  # noqa: E402
+from multigrid.envs.blockedunlockpickup import BlockedUnlockPickupEnv  # noqa: E402
+from multigrid.envs.empty import EmptyEnv  # noqa: E402
+from multigrid.envs.locked_hallway import LockedHallwayEnv  # noqa: E402
+from multigrid.envs.redbluedoors import RedBlueDoorsEnv  # noqa: E402
+
+KIND = {EmptyEnv: 0, RedBlueDoorsEnv: 1, BlockedUnlockPickupEnv: 2, LockedHallwayEnv: 3}
+TEAM_NAMES = ["red", "green", "blue", "purple", "yellow", "grey"]
+COLORS = list(Color)
+
+
+class OrderRecorder:
+    """Wraps the env's ``np_random`` and remembers the last ``random(size)`` draw."""
+
+    def __init__(self, gen):
+        self._gen = gen
+        self.last = None
+
+    def random(self, size=None):
+        self.last = self._gen.random(size=size)
+        return self.last
+
+    def __getattr__(self, name):
+        return getattr(self._gen, name)
+
+
+def teams_for(num_agents: int) -> dict:
+    """Spread agents over teams the way a user of ``teams=`` would (base.py:185)."""
+    if num_agents <= len(TEAM_NAMES):
+        return {TEAM_NAMES[i]: 1 for i in range(num_agents)}
+    base, extra = divmod(num_agents, len(TEAM_NAMES))
+    return {TEAM_NAMES[i]: base + (1 if i < extra else 0) for i in range(len(TEAM_NAMES))}
+
+
+def agent_rows(env) -> np.ndarray:
+    s = np.asarray(env.agent_states).astype(np.int64)
+    out = np.zeros((s.shape[0], 8), dtype=np.uint8)
+    out[:, 0], out[:, 1] = s[:, 3], s[:, 4]
+    out[:, 2], out[:, 3] = s[:, 2], s[:, 5]
+    out[:, 4:7] = s[:, 6:9]
+    out[:, 7] = s[:, 1]
+    return out
+
+
+def door_meta(env) -> np.ndarray:
+    meta = np.zeros(4, dtype=np.uint8)
+    if isinstance(env, RedBlueDoorsEnv):
+        for (x, y), obj in env.grid.world_objects.items():
+            if obj is env.red_door:
+                meta[0], meta[1] = x, y
+            if obj is env.blue_door:
+                meta[2], meta[3] = x, y
+    return meta
+
+
+def spec_of(env) -> dict:
+    return dict(
+        kind=KIND[type(env)], width=env.width, height=env.height,
+        num_agents=env.num_agents, max_steps=env.max_steps,
+        view_size=env.agents[0].view_size,
+        see_through_walls=bool(env.agents[0].see_through_walls),
+        allow_agent_overlap=bool(env.allow_agent_overlap),
+        joint_reward=bool(env.joint_reward),
+        success_any=env.success_termination_mode == "any",
+        failure_any=env.failure_termination_mode == "any",
+        num_rooms=int(getattr(env, "num_rooms", 0)) if isinstance(env, LockedHallwayEnv) else 0,
+        mission=str(env.mission) if isinstance(env.mission, str) else env.mission.string,
+    )
+
+
+# --- harness edits applied after reset() ("chaos" groups) ----------------------
+
+def free_cells(env):
+    pos = {tuple(p) for p in np.asarray(env.agent_states.pos)}
+    return [(x, y) for x in range(1, env.width - 1) for y in range(1, env.height - 1)
+            if env.grid.get(x, y) is None and (x, y) not in pos]
+
+
+def scatter(env, rng, n, kinds):
+    cells = free_cells(env)
+    rng.shuffle(cells)
+    for (x, y) in cells[:n]:
+        k = kinds[rng.integers(len(kinds))]
+        c = COLORS[rng.integers(len(COLORS))]
+        if k == "goal":
+            obj = Goal()
+        elif k == "lava":
+            obj = Lava()
+        elif k == "floor":
+            obj = Floor(c)
+        elif k == "wall":
+            obj = Wall()
+        elif k == "key":
+            obj = Key(c)
+        elif k == "ball":
+            obj = Ball(c)
+        elif k == "box":
+            obj = Box(c)
+        elif k == "door_open":
+            obj = Door(c, is_open=True)
+        elif k == "door_closed":
+            obj = Door(c)
+        elif k == "door_locked":
+            obj = Door(c, is_locked=True)
+        env.grid.set(x, y, obj)
+
+
+def scramble_agents(env, rng, carry=0.3, terminated=0.0):
+    cells = free_cells(env)
+    rng.shuffle(cells)
+    for k, agent in enumerate(env.agents):
+        if rng.random() < 0.85 and cells:
+            agent.state.pos = cells.pop()
+        agent.state.dir = int(rng.integers(4))
+        if rng.random() < carry:
+            kind = rng.integers(3)
+            c = COLORS[rng.integers(len(COLORS))]
+            agent.state.carrying = [Key, Ball, Box][kind](c)
+        if rng.random() < terminated:
+            agent.state.terminated = True
+
+
+def unlock_doors(env, rng, p=1.0):
+    for (x, y), obj in list(env.grid.world_objects.items()):
+        if isinstance(obj, Door) and obj.is_locked and rng.random() < p:
+            obj.is_locked = False
+            if rng.random() < 0.3:
+                obj.is_open = True
+            env.grid.update(x, y)
+
+
+def face_doors_with_keys(env, rng):
+    """LockedHallway: stand agent k in front of a locked door holding its key."""
+    doors = [((x, y), o) for (x, y), o in env.grid.world_objects.items() if isinstance(o, Door)]
+    rng.shuffle(doors)
+    for agent, ((x, y), door) in zip(env.agents, doors):
+        for d, (dx, dy) in enumerate(((1, 0), (0, 1), (-1, 0), (0, -1))):
+            sx, sy = x - dx, y - dy
+            if 0 < sx < env.width - 1 and 0 < sy < env.height - 1 and env.grid.get(sx, sy) is None:
+                agent.state.pos = (sx, sy)
+                agent.state.dir = d
+                if rng.random() < 0.8:
+                    agent.state.carrying = Key(door.color)
+                break
+
+
+# --- recording ---------------------------------------------------------------
+
+def record_group(name, build_env, n_traj, t_max, seed0, edit=None, action_p=None,
+                 extra_after_done=3, script=None):
+    rng = np.random.default_rng(seed0)
+    trajs = []
+    spec = None
+    for n in range(n_traj):
+        env = build_env()
+        env._RandomMixin__np_random = np.random.default_rng(seed0 * 1000 + n)
+        obs, _ = env.reset(seed=seed0 * 7919 + n)
+        if edit is not None:
+            edit(env, rng, n)
+            obs = env.gen_obs()
+        rec = OrderRecorder(env._np_random)
+        env._np_random = rec
+        if spec is None:
+            spec = spec_of(env)
+        a = env.num_agents
+        v = env.agents[0].view_size
+        tr = dict(
+            layout_grid=env.grid.state.astype(np.uint8).copy(),
+            layout_agents=agent_rows(env), layout_meta=door_meta(env),
+            reset_image=np.stack([obs[i]["image"] for i in range(a)]).astype(np.uint8),
+            actions=[], order=[], image=[], direction=[], reward=[], terminated=[],
+            truncated=[], post_grid=[], post_agents=[])
+        after = 0
+        for t in range(t_max):
+            if script is not None and t < len(script(n)):
+                acts = np.asarray(script(n)[t][:a], dtype=np.int64)
+            elif action_p is None:
+                acts = rng.integers(0, 7, size=a)
+            else:
+                acts = rng.choice(7, size=a, p=action_p)
+            rec.last = None
+            o, r, term, trunc, _ = env.step({i: int(acts[i]) for i in range(a)})
+            order = np.arange(a) if rec.last is None else np.argsort(rec.last)
+            tr["actions"].append(acts.astype(np.uint8))
+            tr["order"].append(order.astype(np.uint8))
+            img = np.stack([o[i]["image"] for i in range(a)])
+            assert img.min() >= 0 and img.max() < 256 and img.shape == (a, v, v, 3)
+            tr["image"].append(img.astype(np.uint8))
+            tr["direction"].append(np.array([int(o[i]["direction"]) for i in range(a)], np.uint8))
+            tr["reward"].append(np.array([float(r[i]) for i in range(a)], np.float64))
+            tr["terminated"].append(np.array([bool(term[i]) for i in range(a)]))
+            tr["truncated"].append(np.array([bool(trunc[i]) for i in range(a)]))
+            tr["post_grid"].append(env.grid.state.astype(np.uint8).copy())
+            tr["post_agents"].append(agent_rows(env))
+            if all(term.values()) or all(trunc.values()):
+                after += 1
+                if after > extra_after_done:
+                    break
+        trajs.append(tr)
+
+    n = len(trajs)
+    lens = np.array([len(t["actions"]) for t in trajs], np.int32)
+    tm = int(lens.max())
+    out = dict(spec=np.array(json.dumps(spec)), length=lens)
+    for key in ("layout_grid", "layout_agents", "layout_meta", "reset_image"):
+        out[key] = np.stack([t[key] for t in trajs])
+    for key in ("actions", "order", "image", "direction", "reward", "terminated",
+                "truncated", "post_grid", "post_agents"):
+        first = trajs[0][key][0]
+        arr = np.zeros((n, tm) + first.shape, dtype=first.dtype)
+        for i, t in enumerate(trajs):
+            arr[i, :len(t[key])] = np.stack(t[key])
+        out[key] = arr
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    nrew = int((out["reward"] != 0).sum())
+    nterm = int(out["terminated"].any(axis=(1, 2)).sum())
+    print(f"{name:28s} traj={n:3d} steps={int(lens.sum()):6d} nonzero_rewards={nrew:5d} "
+          f"traj_with_termination={nterm:3d} size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def record_layouts():
+    """Reference ``reset()`` layouts for fixed seeds (checks the host-side layout generators)."""
+    out = {}
+    for name, agents in (("MultiGrid-Empty-8x8-v0", 2), ("MultiGrid-RedBlueDoors-8x8-v0", 2),
+                         ("MultiGrid-BlockedUnlockPickup-v0", 2),
+                         ("MultiGrid-LockedHallway-4Rooms-v0", 4),
+                         ("MultiGrid-LockedHallway-2Rooms-v0", 2),
+                         ("MultiGrid-LockedHallway-6Rooms-v0", 3),
+                         ("MultiGrid-Empty-16x16-v0", 8), ("MultiGrid-RedBlueDoors-6x6-v0", 3),
+                         ("MultiGrid-Empty-Random-6x6-v0", 3)):
+        cls, kw = CONFIGURATIONS[name]
+        grids, ags, metas, missions = [], [], [], []
+        for seed in range(24):
+            env = make_env(cls, agents, **kw)
+            env._RandomMixin__np_random = np.random.default_rng(seed)
+            env.reset(seed=seed + 100)
+            grids.append(env.grid.state.astype(np.uint8).copy())
+            ags.append(agent_rows(env))
+            metas.append(door_meta(env))
+            m = env.mission
+            missions.append(m if isinstance(m, str) else m.string)
+        key = name.replace("MultiGrid-", "").replace("-", "_")
+        out[key + "__grid"] = np.stack(grids)
+        out[key + "__agents"] = np.stack(ags)
+        out[key + "__meta"] = np.stack(metas)
+        out[key + "__mission"] = np.array(missions)
+        out[key + "__num_agents"] = np.array(agents)
+    path = os.path.join(HERE, "layouts.npz")
+    np.savez_compressed(path, **out)
+    print(f"layouts.npz size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+BIASED = np.array([0.12, 0.12, 0.36, 0.12, 0.08, 0.18, 0.02])
+TOGGLY = np.array([0.10, 0.10, 0.25, 0.05, 0.05, 0.43, 0.02])
+
+
+def main():
+    cfg = CONFIGURATIONS
+    # ---- the five BASELINE configurations, untouched reference layouts, uniform actions
+    record_group("cfg1_empty8", lambda: make_env(*_ck(cfg["MultiGrid-Empty-8x8-v0"], 2)), 6, 262, 11)
+    record_group("cfg2_redbluedoors8", lambda: make_env(*_ck(cfg["MultiGrid-RedBlueDoors-8x8-v0"], 2)), 8, 120, 12)
+    record_group("cfg3_blockedunlockpickup", lambda: make_env(*_ck(cfg["MultiGrid-BlockedUnlockPickup-v0"], 2)), 10, 150, 13,
+                 action_p=None)
+    record_group("cfg3_blockedunlockpickup_biased", lambda: make_env(*_ck(cfg["MultiGrid-BlockedUnlockPickup-v0"], 2)), 10, 200, 14,
+                 action_p=BIASED)
+    record_group("cfg4_lockedhallway4", lambda: make_env(*_ck(cfg["MultiGrid-LockedHallway-4Rooms-v0"], 4)), 6, 150, 15)
+    record_group("cfg4_lockedhallway4_biased", lambda: make_env(*_ck(cfg["MultiGrid-LockedHallway-4Rooms-v0"], 4)), 6, 250, 16,
+                 action_p=BIASED)
+    record_group("cfg5_empty16", lambda: make_env(*_ck(cfg["MultiGrid-Empty-16x16-v0"], 8)), 4, 120, 17)
+    record_group("cfg5_empty16_nooverlap",
+                 lambda: make_env(*_ck(cfg["MultiGrid-Empty-16x16-v0"], 8), allow_agent_overlap=False), 4, 120, 18,
+                 action_p=BIASED)
+    # short episodes: truncation, rewards late in the episode
+    record_group("short_empty8", lambda: make_env(EmptyEnv, 2, size=8, max_steps=24), 4, 30, 19, action_p=BIASED)
+    record_group("short_lockedhallway2", lambda: make_env(LockedHallwayEnv, 2, num_rooms=2, max_steps=30), 4, 36, 20,
+                 action_p=BIASED)
+
+    # ---- harness-edited start states
+    allk = ["goal", "lava", "floor", "wall", "key", "ball", "box", "door_open", "door_closed", "door_locked"]
+
+    def chaos_empty(flags):
+        def build():
+            env = make_env(EmptyEnv, flags["agents"], view=flags.get("view", 7), size=flags.get("size", 9),
+                           max_steps=flags.get("max_steps", 60),
+                           allow_agent_overlap=flags["overlap"], joint_reward=flags["joint"],
+                           success_termination_mode=flags["succ"], failure_termination_mode=flags["fail"])
+            for ag in env.agents:
+                ag.see_through_walls = flags["see"]
+            return env
+
+        def edit(env, rng, n):
+            scatter(env, rng, flags.get("objects", 16), allk)
+            scramble_agents(env, rng, carry=0.35, terminated=flags.get("terminated", 0.0))
+        return build, edit
+
+    for name, flags in (
+        ("chaos_empty_a", dict(agents=3, overlap=False, joint=False, succ="all", fail="all", see=False)),
+        ("chaos_empty_b", dict(agents=3, overlap=True, joint=True, succ="any", fail="any", see=False)),
+        ("chaos_empty_c", dict(agents=4, overlap=False, joint=True, succ="all", fail="any", see=True,
+                               terminated=0.25)),
+        ("chaos_empty_d", dict(agents=2, overlap=True, joint=False, succ="any", fail="all", see=False,
+                               size=7, objects=9)),
+        ("chaos_single", dict(agents=1, overlap=True, joint=False, succ="all", fail="all", see=False)),
+        ("chaos_view5", dict(agents=3, overlap=False, joint=False, succ="all", fail="all", see=False, view=5)),
+        ("chaos_view3", dict(agents=2, overlap=True, joint=False, succ="any", fail="all", see=False, view=3)),
+        ("chaos_wide", dict(agents=6, overlap=False, joint=False, succ="all", fail="all", see=False,
+                            size=12, objects=30, terminated=0.15)),
+    ):
+        build, edit = chaos_empty(flags)
+        record_group(name, build, 8, 70, zlib.crc32(name.encode()) % 1000 + 30, edit=edit, action_p=BIASED)
+
+    # RedBlueDoors with usable doors (the fork creates them locked with no key in the world)
+    def rbd_edit(env, rng, n):
+        unlock_doors(env, rng)
+        scramble_agents(env, rng, carry=0.0)
+        if n % 2 == 0:  # start next to a door, facing it
+            door = env.blue_door if n % 4 == 0 else env.red_door
+            for (x, y), o in env.grid.world_objects.items():
+                if o is door:
+                    env.agents[0].state.pos = (x - 1, y) if o is env.blue_door else (x + 1, y)
+                    env.agents[0].state.dir = 0 if o is env.blue_door else 2
+    record_group("chaos_redbluedoors", lambda: make_env(RedBlueDoorsEnv, 2, size=8, max_steps=80),
+                 16, 60, 41, edit=rbd_edit, action_p=TOGGLY)
+    record_group("chaos_redbluedoors_all",
+                 lambda: make_env(RedBlueDoorsEnv, 3, size=6, max_steps=80,
+                                  success_termination_mode="all", failure_termination_mode="all",
+                                  joint_reward=False),
+                 16, 70, 42, edit=rbd_edit, action_p=TOGGLY)
+
+    def bup_edit(env, rng, n):
+        scatter(env, rng, 3, ["key", "ball", "floor", "door_open"])
+        if n % 3 == 0:
+            unlock_doors(env, rng)
+        if n % 2 == 0:
+            for (x, y), o in env.grid.world_objects.items():
+                if isinstance(o, Door):
+                    env.agents[0].state.carrying = Key(o.color)
+        scramble_agents(env, rng, carry=0.0)
+        if n % 4 == 1:  # stand next to the target box
+            for (x, y), o in env.grid.world_objects.items():
+                if o is env.obj and env.grid.get(x - 1, y) is None:
+                    env.agents[1].state.pos = (x - 1, y)
+                    env.agents[1].state.dir = 0
+    record_group("chaos_blockedunlockpickup", lambda: make_env(BlockedUnlockPickupEnv, 2, max_steps=90),
+                 16, 80, 43, edit=bup_edit, action_p=BIASED)
+
+    def lh_edit(env, rng, n):
+        if n % 2 == 0:
+            face_doors_with_keys(env, rng)
+        else:
+            scramble_agents(env, rng, carry=0.0)
+            for ag in env.agents:
+                if rng.random() < 0.7:
+                    ag.state.carrying = Key(COLORS[rng.integers(6)])
+
+    def lh_script(n):
+        return [[5] * 8] if n % 4 == 0 else []
+    record_group("chaos_lockedhallway4", lambda: make_env(LockedHallwayEnv, 4, num_rooms=4, max_steps=120),
+                 12, 80, 44, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    record_group("chaos_lockedhallway2", lambda: make_env(LockedHallwayEnv, 2, num_rooms=2, max_steps=60,
+                                                           joint_reward=False),
+                 12, 50, 45, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    record_group("chaos_lockedhallway6", lambda: make_env(LockedHallwayEnv, 6, num_rooms=6, max_steps=100),
+                 6, 60, 46, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    record_layouts()
+
+
+def _ck(entry, agents):
+    cls, kw = entry
+    return (cls, agents), kw
+
+
+def make_env(*args, **kw):
+    """``make_env(cls, agents, **kw)`` or ``make_env((cls, agents), registry_kwargs, **kw)``."""
+    if len(args) == 2 and isinstance(args[0], tuple):
+        (cls, agents), base_kw = args
+        kw = dict(base_kw, **kw)
+    else:
+        cls, agents = args[0], args[1]
+    view = kw.pop("view", 7)
+    return cls(agents=agents, teams=teams_for(agents), policies_map={}, agent_view_size=view, **kw)
+
+
+if __name__ == "__main__":
+    main()

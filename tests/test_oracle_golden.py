@@ -1,0 +1,38 @@
+"""The Python restatement (oracle/pyref.py) replays every reference trajectory bit for bit."""
+import numpy as np
+import pytest
+
+from golden_util import group_names, load_group
+from oracle import pyref
+
+
+def make_spec(spec):
+    return pyref.EnvSpec(**spec)
+
+
+@pytest.mark.parametrize("name", group_names())
+@pytest.mark.parametrize("fast_obs", [False, True])
+def test_pyref_replays_reference(name, fast_obs):
+    spec, d = load_group(name)
+    a = spec["num_agents"]
+    for n in range(len(d["length"])):
+        env = pyref.Env(make_spec(spec), fast_obs=fast_obs)
+        obs = env.load_layout(d["layout_grid"][n], d["layout_agents"][n], d["layout_meta"][n])
+        img0 = np.stack([obs[i]["image"] for i in range(a)])
+        np.testing.assert_array_equal(img0, d["reset_image"][n], err_msg=f"{name}[{n}] reset obs")
+        for t in range(int(d["length"][n])):
+            acts = d["actions"][n, t]
+            o, r, term, trunc, _ = env.step({i: int(acts[i]) for i in range(a)}, d["order"][n, t])
+            where = f"{name}[{n}] step {t}"
+            img = np.stack([o[i]["image"] for i in range(a)])
+            np.testing.assert_array_equal(img, d["image"][n, t], err_msg=where + " image")
+            np.testing.assert_array_equal([int(o[i]["direction"]) for i in range(a)],
+                                          d["direction"][n, t], err_msg=where + " direction")
+            np.testing.assert_array_equal([float(r[i]) for i in range(a)], d["reward"][n, t],
+                                          err_msg=where + " reward")
+            np.testing.assert_array_equal([term[i] for i in range(a)], d["terminated"][n, t],
+                                          err_msg=where + " terminated")
+            np.testing.assert_array_equal([trunc[i] for i in range(a)], d["truncated"][n, t],
+                                          err_msg=where + " truncated")
+            np.testing.assert_array_equal(env.grid, d["post_grid"][n, t], err_msg=where + " grid")
+            np.testing.assert_array_equal(env.agents, d["post_agents"][n, t], err_msg=where + " agents")
