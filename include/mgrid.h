@@ -1,0 +1,143 @@
+/*
+ * mgrid.h - C ABI of libmgrid_hip.so: a batched MultiGrid simulator for AMD MI355X (gfx950).
+ *
+ * The reference (heng2j/multigrid) has no FFI seam on this path: its boundary is the Python
+ * class surface of `MultiGridEnv` (multigrid/base.py:37).  Each entry point below names the
+ * reference method it replaces for a whole batch of independent environments.  All pointers
+ * suffixed `_dev` are device pointers owned by the caller (e.g. PyTorch-ROCm tensors); the
+ * library owns only its internal state buffers.  Every launch is asynchronous on the
+ * `stream` argument (a `hipStream_t` passed as `void*`; NULL = the default stream).
+ *
+ * Every function returns 0 on success or a negative MG_E* code and never throws;
+ * `mg_last_error` describes the most recent failure.  Calls on one handle must be
+ * serialised by the caller.
+ *
+ * Array layouts at the boundary are the reference's own:
+ *   grid     uint8 [E][W][H][3]  (type, color, state) per cell, x-major  multigrid/core/grid.py:53
+ *   agents   uint8 [E][A][8]     x y dir terminated carry_type carry_color carry_state color
+ *                                (the AgentState row of multigrid/core/agent.py:266-275 without
+ *                                its constant type column, position first)
+ *   meta     uint8 [E][4]        RedBlueDoors: red_x red_y blue_x blue_y (multigrid/envs/
+ *                                redbluedoors.py:161-168); zeros for the other kinds
+ *   image    uint8 [E][A][V][V][3]  obs["image"] of multigrid/base.py:430-436 (int64 there)
+ * Cell fields are limited to type < 16, state < 16, color < 128 (the reference uses 11 / 7 / 6).
+ */
+#ifndef MGRID_H
+#define MGRID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+/* error codes */
+#define MG_OK 0
+#define MG_EINVAL (-1)  /* bad argument / unsupported configuration */
+#define MG_EHIP (-2)    /* a HIP runtime call failed */
+#define MG_ESTATE (-3)  /* call order violated (e.g. step before layouts were uploaded) */
+
+/* environment kinds (which post-step hook runs) */
+#define MG_KIND_EMPTY 0               /* multigrid/envs/empty.py            - no hook */
+#define MG_KIND_REDBLUEDOORS 1        /* multigrid/envs/redbluedoors.py:170-187 */
+#define MG_KIND_BLOCKEDUNLOCKPICKUP 2 /* multigrid/envs/blockedunlockpickup.py:160-169 */
+#define MG_KIND_LOCKEDHALLWAY 3       /* multigrid/envs/locked_hallway.py:193-217 */
+
+/* what happens to an environment whose episode ended in this step */
+#define MG_AUTORESET_NONE 0      /* nothing: the caller resets with mg_reset (reference behaviour) */
+#define MG_AUTORESET_SAME_STEP 1 /* state and the returned image/direction are those of the next
+                                    episode's start, reward/terminated/truncated those of the step
+                                    that ended (gymnasium SyncVectorEnv as used at
+                                    multigrid/scripts/train_ppo_cleanrl.py:366,517) */
+#define MG_AUTORESET_NEXT_STEP 2 /* terminal image returned, state reset before the next step */
+
+typedef struct MgConfig {
+    int32_t kind;                /* MG_KIND_* */
+    int32_t width, height;       /* grid size W, H                      base.py:162-165 */
+    int32_t num_agents;          /* A                                    base.py:172-178 */
+    int32_t view_size;           /* V: 3, 5 or 7                         base.py:96 */
+    int32_t max_steps;           /*                                      base.py:94 */
+    int32_t see_through_walls;   /*                                      base.py:95 */
+    int32_t allow_agent_overlap; /*                                      base.py:97 */
+    int32_t joint_reward;        /*                                      base.py:98 */
+    int32_t success_any;         /* success_termination_mode == "any"    base.py:99 */
+    int32_t failure_any;         /* failure_termination_mode == "any"    base.py:100 */
+    int32_t num_rooms;           /* LockedHallway only                   locked_hallway.py:129 */
+    int32_t num_envs;            /* E: environments held by this handle */
+    int32_t device;              /* HIP device ordinal */
+    int32_t autoreset;           /* MG_AUTORESET_* */
+    int32_t env_id_offset;       /* global index of environment 0 (sharded runs); it seeds the
+                                    layout choice and the on-device agent-order generator */
+    uint64_t seed;               /* seed of the on-device agent-order generator */
+} MgConfig;
+
+/* Caller-owned device output buffers of one step / reset.  Any pointer may be NULL to skip it. */
+typedef struct MgOut {
+    uint8_t *image_dev;      /* [E][A][V][V][3] */
+    uint8_t *direction_dev;  /* [E][A]  obs["direction"]                 base.py:434 */
+    float *reward_dev;       /* [E][A]                                   base.py:454,560-562 */
+    uint8_t *terminated_dev; /* [E][A]                                   base.py:400 + hooks */
+    uint8_t *truncated_dev;  /* [E][A]                                   base.py:401-402 */
+} MgOut;
+
+typedef struct MgEnv *MgHandle;
+
+int mg_abi_version(void);
+
+/* Replaces MultiGridEnv.__init__ (multigrid/base.py:87-245) for E environments. */
+int mg_create(const MgConfig *cfg, MgHandle *out);
+int mg_destroy(MgHandle h);
+
+/* Text of the last error on this handle (or of the last failed mg_create when h is NULL). */
+const char *mg_last_error(MgHandle h);
+
+/* Uploads N start states produced on the host by the `_gen_grid` layout generators
+ * (multigrid/envs/empty.py:152, redbluedoors.py:141, blockedunlockpickup.py:136,
+ * locked_hallway.py:146).  HOST pointers; copied, synchronous. */
+int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, const uint8_t *meta,
+                      int32_t n);
+
+/* Replaces MultiGridEnv.reset (multigrid/base.py:310-362).  `layout_idx_dev` int32[E] picks the
+ * start state per environment (NULL: environment e takes layout (env_id_offset + e +
+ * 7919 * episode) mod N).  `mask_dev` uint8[E] restricts the reset to environments whose byte is
+ * non-zero (NULL: all).  image/direction of the reset environments are written; reward,
+ * terminated and truncated are not touched. */
+int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev, const MgOut *out,
+             void *stream);
+
+/* Replaces MultiGridEnv.step (multigrid/base.py:364-408) plus the environment's own step hook.
+ * `actions_dev` uint8[E][A] (multigrid/core/actions.py:4-15).  `order_dev` uint8[E][A] is the
+ * order in which agents act, i.e. the argsort drawn at multigrid/base.py:457-461; NULL draws a
+ * uniform random permutation per environment and step on the device. */
+int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out,
+            void *stream);
+
+/* Replaces MultiGridEnv.gen_obs (multigrid/base.py:410-438): image and direction of the current
+ * state of every environment. */
+int mg_gen_obs(MgHandle h, const MgOut *out, void *stream);
+
+/* Debug / parity access to the full state in the reference's layouts (see the top of this file).
+ * steps int32[E] = step_count (base.py:350,395); flags uint8[E]: bits 0-5 LockedHallway doors
+ * already rewarded, by door colour (locked_hallway.py:204-205); bit 7: RedBlueDoors blue door
+ * object re-closed after a failure while its grid cell still reads open (redbluedoors.py:185).
+ * Any pointer may be NULL. */
+int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *meta_dev,
+                 int32_t *steps_dev, uint8_t *flags_dev, void *stream);
+int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
+                 const uint8_t *meta_dev, const int32_t *steps_dev, const uint8_t *flags_dev,
+                 void *stream);
+
+/* Episode statistics accumulated on the device since creation, copied to a DEVICE buffer of
+ * MG_NUM_STATS int64: [0] finished episodes, [1] sum of their lengths, [2] episodes ended by
+ * termination, [3] by truncation, [4] sum of all rewards paid, in units of 2^-24, [5] steps
+ * taken (launches), [6..7] reserved.  (The reference keeps no such counters; its callers sum
+ * them on the host, multigrid/utils/training_utilis.py:291-367.) */
+#define MG_NUM_STATS 8
+int mg_stats(MgHandle h, int64_t *stats_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGRID_H */

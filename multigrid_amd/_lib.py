@@ -1,0 +1,92 @@
+"""ctypes binding of ``libmgrid_hip.so`` (declared in ``include/mgrid.h``).
+
+There is no CPU fallback: if the HIP library has not been built, importing a symbol
+from here raises, and every product path stops with it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libmgrid_hip.so")
+SRC_PATH = os.path.join(PKG_DIR, "csrc", "mgrid.hip")
+INCLUDE_DIR = os.path.join(ROOT, "include")
+
+MG_OK = 0
+KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
+AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
+NUM_STATS = 8
+
+EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts",
+           "mg_reset", "mg_step", "mg_gen_obs", "mg_get_state", "mg_set_state", "mg_stats")
+
+
+class MgConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "kind", "width", "height", "num_agents", "view_size", "max_steps", "see_through_walls",
+        "allow_agent_overlap", "joint_reward", "success_any", "failure_any", "num_rooms",
+        "num_envs", "device", "autoreset", "env_id_offset")] + [("seed", ctypes.c_uint64)]
+
+
+class MgOut(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(SRC_PATH),
+                                              os.path.getmtime(os.path.join(INCLUDE_DIR, "mgrid.h"))):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (there is no CPU fallback for the MI355X path)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32 = ctypes.c_void_p, ctypes.c_int32
+        L.mg_abi_version.restype = ctypes.c_int
+        L.mg_create.argtypes = [ctypes.POINTER(MgConfig), ctypes.POINTER(vp)]
+        L.mg_destroy.argtypes = [vp]
+        L.mg_last_error.argtypes = [vp]
+        L.mg_last_error.restype = ctypes.c_char_p
+        L.mg_upload_layouts.argtypes = [vp, vp, vp, vp, i32]
+        L.mg_reset.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
+        L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
+        L.mg_gen_obs.argtypes = [vp, ctypes.POINTER(MgOut), vp]
+        L.mg_get_state.argtypes = [vp] * 7
+        L.mg_set_state.argtypes = [vp] * 7
+        L.mg_stats.argtypes = [vp, vp, vp]
+        for name in EXPORTS:
+            if name not in ("mg_last_error",):
+                getattr(L, name).restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+class MgError(RuntimeError):
+    pass
+
+
+def check(rc: int, handle=None):
+    if rc != MG_OK:
+        msg = lib().mg_last_error(handle)
+        raise MgError(f"libmgrid_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,166 @@
+"""``BatchedMultiGrid``: E independent MultiGrid environments resident on one MI355X.
+
+Host-side mirror of ``MultiGridEnv`` (multigrid/base.py:37) for a whole batch: ``reset`` /
+``step`` / ``gen_obs`` launch the HIP kernels of ``libmgrid_hip.so`` on the current torch
+stream and return PyTorch-ROCm tensors that the kernels wrote in place (zero-copy).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MgConfig, MgOut, check
+
+
+@dataclass
+class StepOutput:
+    image: torch.Tensor       # uint8 [E, A, V, V, 3]
+    direction: torch.Tensor   # uint8 [E, A]
+    reward: torch.Tensor      # float32 [E, A]
+    terminated: torch.Tensor  # uint8 [E, A]
+    truncated: torch.Tensor   # uint8 [E, A]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class BatchedMultiGrid:
+    """``spec`` is a dict with the keys of ``MgConfig`` up to ``num_rooms`` (see include/mgrid.h)."""
+
+    def __init__(self, spec: dict, num_envs: int, device: int | str | torch.device = 0,
+                 autoreset: int = _lib.AUTORESET_NONE, env_id_offset: int = 0, seed: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedMultiGrid needs a ROCm GPU (no CPU fallback)")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.device = dev
+        self.spec = dict(spec)
+        self.E, self.A, self.V = int(num_envs), int(spec["num_agents"]), int(spec["view_size"])
+        self.W, self.H = int(spec["width"]), int(spec["height"])
+        cfg = MgConfig(
+            kind=int(spec["kind"]), width=self.W, height=self.H, num_agents=self.A,
+            view_size=self.V, max_steps=int(spec["max_steps"]),
+            see_through_walls=int(bool(spec["see_through_walls"])),
+            allow_agent_overlap=int(bool(spec["allow_agent_overlap"])),
+            joint_reward=int(bool(spec["joint_reward"])), success_any=int(bool(spec["success_any"])),
+            failure_any=int(bool(spec["failure_any"])), num_rooms=int(spec.get("num_rooms", 0)),
+            num_envs=self.E, device=dev.index or 0, autoreset=int(autoreset),
+            env_id_offset=int(env_id_offset), seed=int(seed))
+        self._h = ctypes.c_void_p()
+        check(_lib.lib().mg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        e, a, v = self.E, self.A, self.V
+        self.out = StepOutput(
+            image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev),
+            direction=torch.zeros((e, a), dtype=torch.uint8, device=dev),
+            reward=torch.zeros((e, a), dtype=torch.float32, device=dev),
+            terminated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
+            truncated=torch.zeros((e, a), dtype=torch.uint8, device=dev))
+        self._mgout = self._make_out(self.out)
+        self.num_layouts = 0
+
+    # -- plumbing -----------------------------------------------------------------
+    @staticmethod
+    def _make_out(o: StepOutput) -> MgOut:
+        return MgOut(o.image.data_ptr(), o.direction.data_ptr(), o.reward.data_ptr(),
+                     o.terminated.data_ptr(), o.truncated.data_ptr())
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev_u8(self, x, shape):
+        t = torch.as_tensor(x)
+        if t.dtype != torch.uint8 or t.device != self.device:
+            t = t.to(device=self.device, dtype=torch.uint8)
+        t = t.contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            _lib.lib().mg_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- API ----------------------------------------------------------------------
+    def upload_layouts(self, grids: np.ndarray, agents: np.ndarray, meta: Optional[np.ndarray] = None):
+        """Start states from the host-side layout generators (``multigrid_amd.layouts``)."""
+        grids = np.ascontiguousarray(grids, np.uint8)
+        agents = np.ascontiguousarray(agents, np.uint8)
+        n = grids.shape[0]
+        if grids.shape != (n, self.W, self.H, 3) or agents.shape != (n, self.A, 8):
+            raise ValueError(f"bad layout shapes {grids.shape} {agents.shape}")
+        meta = np.zeros((n, 4), np.uint8) if meta is None else np.ascontiguousarray(meta, np.uint8)
+        check(_lib.lib().mg_upload_layouts(self._h, grids.ctypes.data, agents.ctypes.data,
+                                           meta.ctypes.data, n), self._h)
+        self.num_layouts = n
+
+    def reset(self, layout_idx=None, mask=None, out: Optional[StepOutput] = None) -> StepOutput:
+        """``MultiGridEnv.reset`` (multigrid/base.py:310) for all (or the masked) environments."""
+        li = None
+        if layout_idx is not None:
+            li = torch.as_tensor(layout_idx).to(device=self.device, dtype=torch.int32).contiguous()
+            assert li.shape == (self.E,)
+        mk = None if mask is None else self._dev_u8(mask, (self.E,))
+        o = self.out if out is None else out
+        mo = self._mgout if out is None else self._make_out(out)
+        check(_lib.lib().mg_reset(self._h, _ptr(li), _ptr(mk), ctypes.byref(mo), self._stream()), self._h)
+        return o
+
+    def step(self, actions, order=None, out: Optional[StepOutput] = None) -> StepOutput:
+        """``MultiGridEnv.step`` (multigrid/base.py:364) for every environment."""
+        act = self._dev_u8(actions, (self.E, self.A))
+        od = None if order is None else self._dev_u8(order, (self.E, self.A))
+        o = self.out if out is None else out
+        mo = self._mgout if out is None else self._make_out(out)
+        check(_lib.lib().mg_step(self._h, _ptr(act), _ptr(od), ctypes.byref(mo), self._stream()), self._h)
+        return o
+
+    def gen_obs(self, out: Optional[StepOutput] = None) -> StepOutput:
+        """``MultiGridEnv.gen_obs`` (multigrid/base.py:410)."""
+        o = self.out if out is None else out
+        mo = self._mgout if out is None else self._make_out(out)
+        check(_lib.lib().mg_gen_obs(self._h, ctypes.byref(mo), self._stream()), self._h)
+        return o
+
+    def get_state(self):
+        """Grid, agent rows, door metadata, step counts and flags in the reference's layouts."""
+        e, dev = self.E, self.device
+        grid = torch.empty((e, self.W, self.H, 3), dtype=torch.uint8, device=dev)
+        agents = torch.empty((e, self.A, 8), dtype=torch.uint8, device=dev)
+        meta = torch.empty((e, 4), dtype=torch.uint8, device=dev)
+        steps = torch.empty((e,), dtype=torch.int32, device=dev)
+        flags = torch.empty((e,), dtype=torch.uint8, device=dev)
+        check(_lib.lib().mg_get_state(self._h, _ptr(grid), _ptr(agents), _ptr(meta), _ptr(steps),
+                                      _ptr(flags), self._stream()), self._h)
+        return dict(grid=grid, agents=agents, meta=meta, steps=steps, flags=flags)
+
+    def set_state(self, grid=None, agents=None, meta=None, steps=None, flags=None):
+        e = self.E
+        g = None if grid is None else self._dev_u8(grid, (e, self.W, self.H, 3))
+        a = None if agents is None else self._dev_u8(agents, (e, self.A, 8))
+        m = None if meta is None else self._dev_u8(meta, (e, 4))
+        f = None if flags is None else self._dev_u8(flags, (e,))
+        s = None
+        if steps is not None:
+            s = torch.as_tensor(steps).to(device=self.device, dtype=torch.int32).contiguous()
+        check(_lib.lib().mg_set_state(self._h, _ptr(g), _ptr(a), _ptr(m), _ptr(s), _ptr(f),
+                                      self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+
+    def stats(self) -> torch.Tensor:
+        """int64[8] device tensor of episode statistics (see ``mg_stats`` in include/mgrid.h)."""
+        t = torch.zeros((_lib.NUM_STATS,), dtype=torch.int64, device=self.device)
+        check(_lib.lib().mg_stats(self._h, _ptr(t), self._stream()), self._h)
+        return t

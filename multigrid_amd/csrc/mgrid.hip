@@ -1,0 +1,1031 @@
+// libmgrid_hip.so - batched MultiGrid step / reset / gen_obs for gfx950 (MI355X).
+//
+// Execution model
+// ---------------
+// One 64-lane wavefront (= one workgroup) owns a TILE of NE consecutive environments with
+// NE * A <= 64, and runs four phases on it, all through LDS:
+//   stage    the tile's header block and grid block are copied HBM -> LDS with 16-byte loads;
+//   act      one lane per ENVIRONMENT replays the agents' actions in the given order
+//            (the reference's sequential handle_actions loop), then the environment hook;
+//   observe  one lane per AGENT walks its V x V view over the LDS grid, runs the visibility
+//            scan on 7-bit row masks in registers and writes the image bytes into an LDS
+//            stream that mirrors the output tensor;
+//   write    the image stream leaves as aligned 16-byte stores, the per-agent scalars as one
+//            coalesced element per lane, and the header block as 16-byte stores.
+//
+// Device state (per handle)
+// -------------------------
+//   hdr   [E][HS] bytes, HS = 16 + 8 * roundup2(A):
+//           int32 step_count | uint32 episode | uint8 flags | 3 pad | uint8 meta[4] | agent rows
+//           agent row = x y dir terminated carry_type carry_color carry_state color
+//   grid  [E][GS] bytes, GS = roundup16(2 * W * H): one uint16 per cell, index x * H + y,
+//           bits 0-3 type, 4-7 state, 8-14 color, 15 "opaque" (wall, or door that is not open).
+//   pool_hdr / pool_grid: the uploaded start states in the same two formats.
+// The step kernel reads hdr + grid once and writes hdr back plus only the cells that changed.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mgrid.h"
+
+namespace {
+
+// ---- encodings (multigrid/core/constants.py:32-102, multigrid/core/actions.py:4-15) ----------
+enum : int { T_UNSEEN, T_EMPTY, T_WALL, T_FLOOR, T_DOOR, T_KEY, T_BALL, T_BOX, T_GOAL, T_LAVA, T_AGENT };
+enum : int { S_OPEN, S_CLOSED, S_LOCKED };
+enum : int { ACT_LEFT, ACT_RIGHT, ACT_FORWARD, ACT_PICKUP, ACT_DROP, ACT_TOGGLE, ACT_DONE };
+enum : int { R_X, R_Y, R_DIR, R_TERM, R_CT, R_CC, R_CS, R_COLOR };
+
+constexpr uint32_t FLAG_LH_MASK = 0x3F;  // LockedHallway: doors already rewarded, by colour
+constexpr uint32_t FLAG_OVER = 0x40;     // episode already counted as finished
+constexpr uint32_t FLAG_STALE = 0x80;    // RedBlueDoors: blue door object closed, cell reads open
+
+constexpr int H_STEP = 0, H_EPISODE = 4, H_FLAGS = 8, H_META = 12, H_ROWS = 16;
+constexpr uint32_t LAYOUT_STRIDE = 7919;  // layout of episode k of env g: (g + 7919 k) mod N
+
+constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
+
+struct KParams {
+    // configuration
+    int kind, W, H, A, max_steps;
+    int overlap, joint, succ_any, fail_any, num_rooms, autoreset;
+    int E, NE, HS, GS, num_layouts;
+    uint32_t env_offset;
+    uint64_t seed;
+    uint32_t serial;  // launch counter, keys the on-device order generator
+    int mode;
+    // state
+    uint8_t *hdr;
+    uint8_t *grid;
+    const uint8_t *pool_hdr;
+    const uint8_t *pool_grid;
+    int64_t *stats;  // [64][MG_NUM_STATS] shards
+    // inputs
+    const uint8_t *actions;
+    const uint8_t *order;
+    const int32_t *layout_idx;
+    const uint8_t *mask;
+    // outputs
+    uint8_t *image;
+    uint8_t *direction;
+    float *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    // LDS carve-up (byte offsets)
+    int o_hdr, o_grid, o_img, o_act, o_ord, o_tout, o_oterm, o_flag, o_dirty, o_rew;
+};
+
+__device__ __forceinline__ uint32_t pack_cell(uint32_t t, uint32_t c, uint32_t s) {
+    // "opaque" restates see_behind() == False, multigrid/utils/obs.py:44-61
+    const uint32_t opaque = (t == T_WALL) | ((t == T_DOOR) & (s != S_OPEN));
+    return t | (s << 4) | (c << 8) | (opaque << 15);
+}
+constexpr uint32_t CELL_EMPTY = T_EMPTY;                        // (1, 0, 0)
+constexpr uint32_t CELL_WALL = T_WALL | (5u << 8) | (1u << 15);  // WALL_ENCODING (2, 5, 0), obs.py:13
+
+// DIR_TO_VEC, multigrid/core/constants.py:20-29
+__device__ __forceinline__ int dir_dx(int d) { return (d == 0) - (d == 2); }
+__device__ __forceinline__ int dir_dy(int d) { return (d == 1) - (d == 3); }
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---- act: one lane per environment -------------------------------------------------------------
+
+struct EnvView {
+    uint8_t *h;        // header block in LDS
+    uint16_t *g;       // grid block in LDS
+    uint8_t *rows;     // agent rows
+    double *rew;       // [A]
+    uint8_t *tout;     // [A] terminated as returned to the caller
+    uint32_t flags;
+    double R;          // _reward(), multigrid/base.py:655-659
+};
+
+// every agent counts, terminated ones included: multigrid/base.py:485,512
+__device__ __forceinline__ bool agent_at(const uint8_t *rows, int A, int x, int y) {
+    bool hit = false;
+    for (int k = 0; k < A; ++k) hit |= (rows[8 * k + R_X] == x) & (rows[8 * k + R_Y] == y);
+    return hit;
+}
+
+// on_success, multigrid/base.py:535-562.  `hook` is false for the calls made from
+// handle_actions with an empty terminations dict (base.py:492), which change no termination
+// in mode "any".
+__device__ __forceinline__ void on_success(const KParams &p, EnvView &ev, int i, bool hook) {
+    if (p.succ_any) {
+        if (hook)
+            for (int k = 0; k < p.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
+    } else {
+        ev.rows[8 * i + R_TERM] = 1;
+        if (hook) ev.tout[i] = 1;
+    }
+    if (p.joint)
+        for (int k = 0; k < p.A; ++k) ev.rew[k] = ev.R;
+    else
+        ev.rew[i] = ev.R;
+}
+
+// on_failure, multigrid/base.py:564-585
+__device__ __forceinline__ void on_failure(const KParams &p, EnvView &ev, int i, bool hook) {
+    if (p.fail_any) {
+        if (hook)
+            for (int k = 0; k < p.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
+    } else {
+        ev.rows[8 * i + R_TERM] = 1;
+        if (hook) ev.tout[i] = 1;
+    }
+}
+
+// MultiGridEnv.step up to (not including) gen_obs, then the subclass hook:
+// multigrid/base.py:395-396,440-533 and redbluedoors.py:176-185,
+// blockedunlockpickup.py:165-167, locked_hallway.py:200-215.
+__device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
+    const int A = p.A, W = p.W, H = p.H;
+    EnvView ev;
+    ev.h = lds + p.o_hdr + slot * p.HS;
+    ev.g = reinterpret_cast<uint16_t *>(lds + p.o_grid + slot * p.GS);
+    ev.rows = ev.h + H_ROWS;
+    ev.rew = reinterpret_cast<double *>(lds + p.o_rew) + slot * A;
+    ev.tout = lds + p.o_tout + slot * A;
+    uint8_t *oterm = lds + p.o_oterm + slot * A;
+    uint16_t *dirty = reinterpret_cast<uint16_t *>(lds + p.o_dirty) + slot * A;
+    const uint8_t *actb = lds + p.o_act + slot * A;
+    uint8_t *ordb = lds + p.o_ord + slot * A;
+
+    const int step = *reinterpret_cast<int *>(ev.h + H_STEP) + 1;  // base.py:395
+    *reinterpret_cast<int *>(ev.h + H_STEP) = step;
+    ev.flags = ev.h[H_FLAGS];
+    const uint32_t was_over = ev.flags & FLAG_OVER;
+    ev.R = 1.0 - 0.9 * (static_cast<double>(step) / static_cast<double>(p.max_steps));
+    const int red_x = ev.h[H_META], red_y = ev.h[H_META + 1];
+    const int blue_x = ev.h[H_META + 2], blue_y = ev.h[H_META + 3];
+    const bool rbd = p.kind == MG_KIND_REDBLUEDOORS;
+
+    if (p.order == nullptr) {
+        // uniform random permutation, keyed by (seed, launch, global environment index);
+        // stands in for np_random.random(A).argsort() of base.py:457-461
+        uint64_t st = mix64(p.seed ^ (static_cast<uint64_t>(p.serial) << 32) ^
+                            (static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env)));
+        for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
+        for (int k = A - 1; k > 0; --k) {
+            st = mix64(st + 0x9E3779B97F4A7C15ull);
+            const int j = static_cast<int>(((st >> 32) * static_cast<uint64_t>(k + 1)) >> 32);
+            const uint8_t t = ordb[k];
+            ordb[k] = ordb[j];
+            ordb[j] = t;
+        }
+    }
+
+    for (int k = 0; k < A; ++k) {
+        ev.rew[k] = 0.0;  // base.py:454
+        dirty[k] = 0xFFFF;
+    }
+
+    for (int n = 0; n < A; ++n) {  // base.py:464
+        const int i = ordb[n];
+        if (i >= A) continue;
+        uint8_t *a = ev.rows + 8 * i;
+        if (a[R_TERM]) continue;  // base.py:467
+        const int act = actb[i];
+        const int dir = a[R_DIR];
+        if (act == ACT_LEFT) { a[R_DIR] = static_cast<uint8_t>((dir + 3) & 3); continue; }   // :471-472
+        if (act == ACT_RIGHT) { a[R_DIR] = static_cast<uint8_t>((dir + 1) & 3); continue; }  // :475-476
+        if (act >= ACT_DONE) continue;                                                        // :527-528
+        const int fx = a[R_X] + dir_dx(dir), fy = a[R_Y] + dir_dy(dir);  // agent.py:153-160
+        if (static_cast<unsigned>(fx) >= static_cast<unsigned>(W) ||
+            static_cast<unsigned>(fy) >= static_cast<unsigned>(H))
+            continue;  // cannot happen inside border walls; keeps the LDS access in range
+        const int ci = fx * H + fy;
+        const uint32_t w = ev.g[ci];
+        const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
+        const bool blue = rbd && fx == blue_x && fy == blue_y;
+        // state of the world OBJECT: equals the cell except for the blue door re-closed by
+        // redbluedoors.py:185 without a grid.update
+        const int so = (blue && (ev.flags & FLAG_STALE)) ? S_CLOSED : s;
+        if (act == ACT_FORWARD) {  // base.py:479-494
+            const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
+                                     (t == T_DOOR && so == S_OPEN);
+            if (!can_overlap) continue;
+            if (!p.overlap && agent_at(ev.rows, A, fx, fy)) continue;
+            a[R_X] = static_cast<uint8_t>(fx);
+            a[R_Y] = static_cast<uint8_t>(fy);
+            if (t == T_GOAL) on_success(p, ev, i, false);
+            if (t == T_LAVA) on_failure(p, ev, i, false);
+        } else if (act == ACT_PICKUP) {  // base.py:497-504
+            if ((t == T_KEY || t == T_BALL || t == T_BOX) && a[R_CT] == T_EMPTY) {
+                a[R_CT] = static_cast<uint8_t>(t);
+                a[R_CC] = static_cast<uint8_t>(c);
+                a[R_CS] = static_cast<uint8_t>(s);
+                ev.g[ci] = CELL_EMPTY;
+                dirty[n] = static_cast<uint16_t>(ci);
+            }
+        } else if (act == ACT_DROP) {  // base.py:507-516
+            if (a[R_CT] != T_EMPTY && t == T_EMPTY && !agent_at(ev.rows, A, fx, fy)) {
+                ev.g[ci] = static_cast<uint16_t>(pack_cell(a[R_CT], a[R_CC], a[R_CS]));
+                a[R_CT] = T_EMPTY;
+                a[R_CC] = 0;
+                a[R_CS] = 0;
+                dirty[n] = static_cast<uint16_t>(ci);
+            }
+        } else {  // toggle, base.py:519-524
+            if (t == T_DOOR) {  // Door.toggle, world_object.py:456-472
+                if (so == S_LOCKED) {
+                    if (a[R_CT] == T_KEY && a[R_CC] == c) {
+                        ev.g[ci] = static_cast<uint16_t>(pack_cell(T_DOOR, c, S_OPEN));
+                        dirty[n] = static_cast<uint16_t>(ci);
+                    }
+                } else {
+                    ev.g[ci] = static_cast<uint16_t>(pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN));
+                    dirty[n] = static_cast<uint16_t>(ci);
+                    if (blue) ev.flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+                }
+            } else if (t == T_BOX) {  // Box.toggle with no contents, world_object.py:653-659
+                ev.g[ci] = CELL_EMPTY;
+                dirty[n] = static_cast<uint16_t>(ci);
+            }
+        }
+    }
+
+    // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
+    for (int k = 0; k < A; ++k) {
+        const uint8_t t = ev.rows[8 * k + R_TERM];
+        ev.tout[k] = t;
+        oterm[k] = t;
+    }
+    const bool trunc = step >= p.max_steps;
+
+    // subclass hooks run on the returned dicts, agents in index order
+    if (rbd) {  // redbluedoors.py:176-185
+        for (int i = 0; i < A; ++i) {
+            if (actb[i] != ACT_TOGGLE) continue;
+            const uint8_t *a = ev.rows + 8 * i;
+            const int fx = a[R_X] + dir_dx(a[R_DIR]), fy = a[R_Y] + dir_dy(a[R_DIR]);
+            if (fx != blue_x || fy != blue_y) continue;
+            const uint32_t w = ev.g[blue_x * H + blue_y];
+            if ((w & 15) != T_DOOR) continue;
+            const int so = (ev.flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((w >> 4) & 15);
+            if (so != S_OPEN) continue;
+            const uint32_t red = ev.g[red_x * H + red_y];
+            if (((red >> 4) & 15) == S_OPEN) {
+                on_success(p, ev, i, true);
+            } else {
+                on_failure(p, ev, i, true);
+                ev.flags |= FLAG_STALE;
+            }
+        }
+    } else if (p.kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
+        for (int i = 0; i < A; ++i)
+            if (ev.rows[8 * i + R_CT] == T_BOX) on_success(p, ev, i, true);
+    } else if (p.kind == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
+        for (int i = 0; i < A; ++i) {
+            if (actb[i] != ACT_TOGGLE) continue;
+            const uint8_t *a = ev.rows + 8 * i;
+            const int fx = a[R_X] + dir_dx(a[R_DIR]), fy = a[R_Y] + dir_dy(a[R_DIR]);
+            if (static_cast<unsigned>(fx) >= static_cast<unsigned>(W) ||
+                static_cast<unsigned>(fy) >= static_cast<unsigned>(H))
+                continue;
+            const uint32_t w = ev.g[fx * H + fy];
+            if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
+            const uint32_t bit = 1u << ((w >> 8) & 7);
+            if (ev.flags & bit & FLAG_LH_MASK) continue;
+            ev.flags |= bit & FLAG_LH_MASK;
+            if (p.joint)
+                for (int k = 0; k < A; ++k) ev.rew[k] += ev.R;
+            else
+                ev.rew[i] += ev.R;
+        }
+        if (__popc(ev.flags & FLAG_LH_MASK) == p.num_rooms)
+            for (int k = 0; k < A; ++k) ev.tout[k] = 1;
+    }
+
+    bool all_term = true;
+    double paid = 0.0;
+    for (int k = 0; k < A; ++k) {
+        all_term &= ev.tout[k] != 0;
+        paid += ev.rew[k];
+    }
+    const bool over = trunc || all_term;
+    if (over) ev.flags |= FLAG_OVER;
+    ev.h[H_FLAGS] = static_cast<uint8_t>(ev.flags);
+
+    uint8_t *fl = lds + p.o_flag + 2 * slot;
+    const bool will_reset = over && p.autoreset != MG_AUTORESET_NONE;
+    fl[0] = trunc ? 1 : 0;
+    fl[1] = will_reset ? 1 : 0;
+
+    // episode statistics: touched only when something happened (rare)
+    int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
+    if (over && !was_over) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+    }
+    if (paid != 0.0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+                  static_cast<unsigned long long>(static_cast<long long>(paid * 16777216.0)));
+
+    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
+    if (!will_reset) {
+        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+        for (int n = 0; n < A; ++n) {
+            const uint32_t ci = dirty[n];
+            if (ci != 0xFFFF) gg[ci] = ev.g[ci];
+        }
+    }
+}
+
+// Draw every live agent into the LDS grid copy, index order, later agents on top
+// (multigrid/utils/obs.py:157-165; single-agent environments draw nothing, obs.py:166-167).
+__device__ __forceinline__ void overlay_env(const KParams &p, uint8_t *lds, int slot) {
+    if (p.A <= 1) return;
+    const uint8_t *rows = lds + p.o_hdr + slot * p.HS + H_ROWS;
+    const uint8_t *oterm = lds + p.o_oterm + slot * p.A;
+    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o_grid + slot * p.GS);
+    for (int k = 0; k < p.A; ++k) {
+        if (oterm[k]) continue;
+        const uint8_t *a = rows + 8 * k;
+        const unsigned x = a[R_X], y = a[R_Y];
+        if (x < static_cast<unsigned>(p.W) && y < static_cast<unsigned>(p.H))
+            g[x * p.H + y] = static_cast<uint16_t>(T_AGENT | (a[R_DIR] << 4) | (a[R_COLOR] << 8));
+    }
+}
+
+// Replace one environment's LDS + HBM state by a start state from the pool
+// (MultiGridEnv.reset, multigrid/base.py:310-362, with the layout precomputed on the host).
+// Executed by the whole wavefront for one slot at a time.
+__device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int slot, int env, int layout,
+                                           uint32_t episode, int lane) {
+    const uint4 *sh = reinterpret_cast<const uint4 *>(p.pool_hdr + static_cast<size_t>(layout) * p.HS);
+    const uint4 *sg = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(layout) * p.GS);
+    uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o_hdr + slot * p.HS);
+    uint4 *dg = reinterpret_cast<uint4 *>(lds + p.o_grid + slot * p.GS);
+    uint4 *gg = reinterpret_cast<uint4 *>(p.grid + static_cast<size_t>(env) * p.GS);
+    for (int i = lane; i < p.HS / 16; i += 64) {
+        uint4 v = sh[i];
+        if (i == 0) v.y = episode;  // keep the environment's own episode counter
+        dh[i] = v;
+    }
+    for (int i = lane; i < p.GS / 16; i += 64) {
+        const uint4 v = sg[i];
+        dg[i] = v;
+        gg[i] = v;
+    }
+}
+
+// ---- observe: one lane per agent ------------------------------------------------------------------
+
+// gen_obs_grid_encoding for one agent: multigrid/utils/obs.py:64-99 (gen_obs_grid :127-203,
+// get_view_exts :272-310, get_vis_mask :231-269), written for a grid that already carries
+// the agent overlay.  Image bytes go to `out` in [u][v][3] order.
+template <int V, bool SEE>
+__device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *row, const uint8_t *gbytes,
+                                              uint8_t *out) {
+    constexpr int HALF = V / 2;
+    const int W = p.W, H = p.H;
+    const int x = row[R_X], y = row[R_Y], dir = row[R_DIR];
+    // forward f and right r unit vectors; view cell (u, v) sits (u - HALF) to the right of and
+    // (V - 1 - v) ahead of the agent, which is the rotation table of obs.py:174-190
+    const int fx = dir_dx(dir), fy = dir_dy(dir);
+    const int rx = dir_dx((dir + 1) & 3), ry = dir_dy((dir + 1) & 3);
+    const bool r_on_x = rx != 0;
+    const int cr = r_on_x ? x : y, lr = r_on_x ? W : H, sr = rx + ry;  // coordinate moved by u
+    const int cf = r_on_x ? y : x, lf = r_on_x ? H : W, sf = fx + fy;  // coordinate moved by v
+    // byte offsets: cell index = X * H + Y, two bytes per cell
+    const int step_u = 2 * (rx * H + ry);
+    const int step_f = 2 * (fx * H + fy);
+    const int base = 2 * (x * H + y);
+
+    // Per-u and per-v: is the world coordinate inside the grid, and the (clamped, always valid)
+    // byte offset contribution.
+    int off_u[V], off_v[V];
+    uint32_t in_u = 0, in_v = 0;
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+        const int c = cr + (u - HALF) * sr;
+        const bool in = static_cast<unsigned>(c) < static_cast<unsigned>(lr);
+        in_u |= (in ? 1u : 0u) << u;
+        off_u[u] = in ? (u - HALF) * step_u : 0;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int c = cf + (V - 1 - v) * sf;
+        const bool in = static_cast<unsigned>(c) < static_cast<unsigned>(lf);
+        in_v |= (in ? 1u : 0u) << v;
+        off_v[v] = base + (in ? (V - 1 - v) * step_f : 0);
+    }
+
+    uint32_t cell[V * V];
+    uint32_t opq[V];  // per view row v: bit u set when cell (u, v) blocks sight
+#pragma unroll
+    for (int v = 0; v < V; ++v) opq[v] = 0;
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+        const uint32_t row_in = ((in_u >> u) & 1u) ? in_v : 0u;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            uint32_t w = *reinterpret_cast<const uint16_t *>(gbytes + off_v[v] + off_u[u]);
+            w = ((row_in >> v) & 1u) ? w : CELL_WALL;  // out of bounds -> wall, obs.py:193-196
+            cell[u * V + v] = w;
+        }
+    }
+    // the agent's own cell shows what it carries, obs.py:201
+    cell[HALF * V + (V - 1)] = pack_cell(row[R_CT], row[R_CC], row[R_CS]);
+
+    if (!SEE) {
+#pragma unroll
+        for (int u = 0; u < V; ++u)
+#pragma unroll
+            for (int v = 0; v < V; ++v) opq[v] |= ((cell[u * V + v] >> 15) & 1u) << u;
+
+        // get_vis_mask, obs.py:231-269, on V-bit rows.  In one row, a visible see-through cell
+        // lights its neighbour in the pass direction; a run of see-through cells therefore
+        // carries like a binary addition: (S + x) ^ S marks every cell from an emitter x to
+        // one past the end of its run.
+        constexpr uint32_t FULL = (1u << V) - 1u;
+        uint32_t vis[V];
+        uint32_t cur = 1u << HALF;  // obs.py:249
+#pragma unroll
+        for (int v = V - 1; v >= 0; --v) {
+            const uint32_t S = ~opq[v] & FULL;
+            // forward pass i = 0 .. V-2 (obs.py:254-259)
+            const uint32_t F = (cur | ((S + (cur & S)) ^ S)) & FULL;
+            const uint32_t EA = F & S & (FULL >> 1);
+            // backward pass i = V-1 .. 1 (obs.py:262-267), same trick on the bit-reversed row
+            const uint32_t rS = __brev(S), rF = __brev(F);
+            const uint32_t B = (F | __brev((rS + (rF & rS)) ^ rS)) & FULL;
+            const uint32_t EB = B & S & (FULL & ~1u);
+            vis[v] = B;
+            cur = (EA | (EA << 1) | EB | (EB >> 1)) & FULL;  // cells lit in the row above
+        }
+#pragma unroll
+        for (int u = 0; u < V; ++u)
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                cell[u * V + v] = ((vis[v] >> u) & 1u) ? cell[u * V + v] : 0u;  // UNSEEN (0,0,0), obs.py:14,97
+    }
+
+#pragma unroll
+    for (int k = 0; k < V * V; ++k) {
+        const uint32_t w = cell[k];
+        out[3 * k + 0] = static_cast<uint8_t>(w & 15);
+        out[3 * k + 1] = static_cast<uint8_t>((w >> 8) & 127);
+        out[3 * k + 2] = static_cast<uint8_t>((w >> 4) & 15);
+    }
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------------
+
+template <int V, bool SEE>
+__global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    constexpr int IMG = 3 * V * V;  // bytes per agent image
+    const int lane = threadIdx.x;
+    const int A = p.A;
+    const int tile = blockIdx.x;
+    const int e0 = tile * p.NE;
+    const int ne = min(p.NE, p.E - e0);
+    const int np = ne * A;
+    const int my_slot = lane / A;          // observe phase: environment slot of this lane's agent
+    const int my_agent = lane - my_slot * A;
+
+    // which environments of the tile take part (reset / obs modes may skip some)
+    bool active = lane < ne;
+    if (p.mode == MODE_RESET && active && p.mask) active = p.mask[e0 + lane] != 0;
+    const uint64_t active_mask = __ballot(active);
+    const bool all_active = active_mask == ((ne == 64) ? ~0ull : ((1ull << ne) - 1ull));
+    if (active_mask == 0) return;
+
+    // ---- stage -------------------------------------------------------------------------------
+    if (p.mode != MODE_RESET) {
+        const uint4 *sh = reinterpret_cast<const uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
+        const uint4 *sg = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0) * p.GS);
+        uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o_hdr);
+        uint4 *dg = reinterpret_cast<uint4 *>(lds + p.o_grid);
+        const int nh = ne * p.HS / 16, ng = ne * p.GS / 16;
+        for (int i0 = 0; i0 < ng; i0 += 64 * 8) {
+            uint4 buf[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = i0 + c * 64 + lane;
+                if (i < ng) buf[c] = sg[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = i0 + c * 64 + lane;
+                if (i < ng) dg[i] = buf[c];
+            }
+        }
+        for (int i = lane; i < nh; i += 64) dh[i] = sh[i];
+        if (p.mode == MODE_STEP && lane < np) {
+            lds[p.o_act + lane] = p.actions[static_cast<size_t>(e0) * A + lane];
+            if (p.order) lds[p.o_ord + lane] = p.order[static_cast<size_t>(e0) * A + lane];
+        }
+    }
+    __syncthreads();
+
+    // ---- reset mode: pull start states from the pool --------------------------------------------
+    if (p.mode == MODE_RESET) {
+        uint64_t m = active_mask;
+        while (m) {
+            const int s = __builtin_ctzll(m);
+            m &= m - 1;
+            const int env = e0 + s;
+            const uint32_t old_episode = *reinterpret_cast<const uint32_t *>(
+                p.hdr + static_cast<size_t>(env) * p.HS + H_EPISODE);
+            const uint32_t episode = p.serial == 0 ? 0u : old_episode + 1u;
+            int layout;
+            if (p.layout_idx)
+                layout = p.layout_idx[env];
+            else
+                layout = static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
+                                           static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
+                                          static_cast<uint64_t>(p.num_layouts));
+            layout = min(max(layout, 0), p.num_layouts - 1);
+            reload_env(p, lds, s, env, layout, episode, lane);
+        }
+        __syncthreads();
+        if (lane < np) lds[p.o_oterm + lane] = lds[p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent + R_TERM];
+        __syncthreads();
+    } else if (p.mode == MODE_OBS) {
+        if (lane < np) lds[p.o_oterm + lane] = lds[p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent + R_TERM];
+        __syncthreads();
+    }
+
+    // ---- act -----------------------------------------------------------------------------------
+    if (p.mode == MODE_STEP) {
+        if (lane < ne) act_env(p, lds, lane, e0 + lane);
+        __syncthreads();
+        if (p.autoreset == MG_AUTORESET_SAME_STEP) {
+            uint64_t m = __ballot(lane < ne && lds[p.o_flag + 2 * lane + 1] != 0);
+            if (m) {
+                while (m) {
+                    const int s = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int env = e0 + s;
+                    const uint32_t episode =
+                        *reinterpret_cast<const uint32_t *>(lds + p.o_hdr + s * p.HS + H_EPISODE) + 1u;
+                    const int layout =
+                        static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
+                                          static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
+                                         static_cast<uint64_t>(p.num_layouts));
+                    __syncthreads();
+                    reload_env(p, lds, s, env, layout, episode, lane);
+                    __syncthreads();
+                    if (lane < A) lds[p.o_oterm + s * A + lane] = lds[p.o_hdr + s * p.HS + H_ROWS + 8 * lane + R_TERM];
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- observe ----------------------------------------------------------------------------------
+    const bool want_img = p.image != nullptr;
+    const size_t out_base = (static_cast<size_t>(e0) * A) * IMG;  // byte offset of the tile's images
+    const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
+    if (want_img) {
+        if (lane < ne && ((active_mask >> lane) & 1)) overlay_env(p, lds, lane);
+        __syncthreads();
+        if (lane < np && ((active_mask >> my_slot) & 1)) {
+            const uint8_t *row = lds + p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent;
+            observe_agent<V, SEE>(p, row, lds + p.o_grid + my_slot * p.GS, lds + p.o_img + shift + lane * IMG);
+        }
+        __syncthreads();
+    }
+
+    // ---- write ----------------------------------------------------------------------------------
+    if (want_img) {
+        // The LDS stream sits `shift` bytes into its buffer so that LDS and HBM agree modulo 16.
+        uint8_t *gdst = p.image + out_base - shift;
+        const int total = shift + np * IMG;
+        const int nchunk = (total + 15) / 16;
+        for (int c = lane; c < nchunk; c += 64) {
+            const int b0 = 16 * c;
+            const bool whole = all_active && b0 >= shift && b0 + 16 <= total;
+            if (whole) {
+                *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o_img + b0);
+            } else {
+                for (int b = b0; b < b0 + 16; ++b) {
+                    if (b < shift || b >= total) continue;
+                    const int slot = ((b - shift) / IMG) / A;
+                    if ((active_mask >> slot) & 1) gdst[b] = lds[p.o_img + b];
+                }
+            }
+        }
+    }
+    if (lane < np && ((active_mask >> my_slot) & 1)) {
+        const size_t o = static_cast<size_t>(e0) * A + lane;
+        const uint8_t *row = lds + p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent;
+        if (p.direction) p.direction[o] = row[R_DIR];
+        if (p.mode == MODE_STEP) {
+            if (p.reward) p.reward[o] = static_cast<float>(reinterpret_cast<const double *>(lds + p.o_rew)[lane]);
+            if (p.terminated) p.terminated[o] = lds[p.o_tout + lane];
+            if (p.truncated) p.truncated[o] = lds[p.o_flag + 2 * my_slot];
+        }
+    }
+
+    if (p.mode == MODE_STEP) {
+        if (p.autoreset == MG_AUTORESET_NEXT_STEP) {
+            uint64_t m = __ballot(lane < ne && lds[p.o_flag + 2 * lane + 1] != 0);
+            if (m) {
+                __syncthreads();
+                while (m) {
+                    const int s = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int env = e0 + s;
+                    const uint32_t episode =
+                        *reinterpret_cast<const uint32_t *>(lds + p.o_hdr + s * p.HS + H_EPISODE) + 1u;
+                    const int layout =
+                        static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
+                                          static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
+                                         static_cast<uint64_t>(p.num_layouts));
+                    __syncthreads();
+                    reload_env(p, lds, s, env, layout, episode, lane);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (p.mode != MODE_OBS) {
+        // header block back to HBM (reset mode: only the environments that were reset)
+        uint4 *dh = reinterpret_cast<uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
+        const uint4 *sh = reinterpret_cast<const uint4 *>(lds + p.o_hdr);
+        const int per = p.HS / 16;
+        for (int i = lane; i < ne * per; i += 64)
+            if ((active_mask >> (i / per)) & 1) dh[i] = sh[i];
+    }
+}
+
+// ---- reference-layout <-> device-layout conversion (debug / parity path) -------------------------------
+
+__global__ void mg_set_state_kernel(KParams p, const uint8_t *grid, const uint8_t *agents, const uint8_t *meta,
+                                    const int32_t *steps, const uint8_t *flags) {
+    const int cells = p.W * p.H;
+    const size_t n = static_cast<size_t>(p.E) * cells;
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t e = i / cells;
+        const int c = static_cast<int>(i - e * cells);
+        if (grid) {
+            const uint8_t *s = grid + i * 3;
+            reinterpret_cast<uint16_t *>(p.grid + e * p.GS)[c] = static_cast<uint16_t>(pack_cell(s[0], s[1], s[2]));
+        }
+        if (c == 0) {
+            uint8_t *h = p.hdr + e * p.HS;
+            if (steps) *reinterpret_cast<int32_t *>(h + H_STEP) = steps[e];
+            if (flags) h[H_FLAGS] = static_cast<uint8_t>(flags[e] & ~FLAG_OVER);
+            if (meta)
+                for (int k = 0; k < 4; ++k) h[H_META + k] = meta[e * 4 + k];
+            if (agents)
+                for (int k = 0; k < p.A * 8; ++k) h[H_ROWS + k] = agents[e * p.A * 8 + k];
+        }
+    }
+}
+
+__global__ void mg_get_state_kernel(KParams p, uint8_t *grid, uint8_t *agents, uint8_t *meta, int32_t *steps,
+                                    uint8_t *flags) {
+    const int cells = p.W * p.H;
+    const size_t n = static_cast<size_t>(p.E) * cells;
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t e = i / cells;
+        const int c = static_cast<int>(i - e * cells);
+        if (grid) {
+            const uint32_t w = reinterpret_cast<const uint16_t *>(p.grid + e * p.GS)[c];
+            uint8_t *d = grid + i * 3;
+            d[0] = static_cast<uint8_t>(w & 15);
+            d[1] = static_cast<uint8_t>((w >> 8) & 127);
+            d[2] = static_cast<uint8_t>((w >> 4) & 15);
+        }
+        if (c == 0) {
+            const uint8_t *h = p.hdr + e * p.HS;
+            if (steps) steps[e] = *reinterpret_cast<const int32_t *>(h + H_STEP);
+            if (flags) flags[e] = h[H_FLAGS] & ~FLAG_OVER;
+            if (meta)
+                for (int k = 0; k < 4; ++k) meta[e * 4 + k] = h[H_META + k];
+            if (agents)
+                for (int k = 0; k < p.A * 8; ++k) agents[e * p.A * 8 + k] = h[H_ROWS + k];
+        }
+    }
+}
+
+__global__ void mg_stats_kernel(const int64_t *shards, int64_t *out, int64_t launches) {
+    const int k = threadIdx.x;
+    if (k >= MG_NUM_STATS) return;
+    int64_t s = 0;
+    for (int i = 0; i < 64; ++i) s += shards[i * MG_NUM_STATS + k];
+    if (k == 5) s = launches;
+    out[k] = s;
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------
+
+struct MgEnv {
+    MgConfig cfg{};
+    KParams kp{};
+    size_t lds_bytes = 0;
+    int num_tiles = 0;
+    uint8_t *hdr = nullptr, *grid = nullptr, *pool_hdr = nullptr, *pool_grid = nullptr;
+    int64_t *stats = nullptr;
+    int num_layouts = 0;
+    bool reset_done = false;
+    uint32_t step_serial = 0;
+    uint32_t reset_serial = 0;
+    int64_t launches = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(MgEnv *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h)
+        h->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define MG_HIP(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return fail(h, MG_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int V>
+void launch_v(const MgEnv *h, const KParams &kp, hipStream_t s) {
+    const dim3 grid(h->num_tiles), block(64);
+    if (h->cfg.see_through_walls)
+        hipLaunchKernelGGL((mg_tile_kernel<V, true>), grid, block, h->lds_bytes, s, kp);
+    else
+        hipLaunchKernelGGL((mg_tile_kernel<V, false>), grid, block, h->lds_bytes, s, kp);
+}
+
+int launch_tile(MgEnv *h, const KParams &kp, hipStream_t s) {
+    switch (h->cfg.view_size) {
+        case 3: launch_v<3>(h, kp, s); break;
+        case 5: launch_v<5>(h, kp, s); break;
+        case 7: launch_v<7>(h, kp, s); break;
+        default: return fail(h, MG_EINVAL, "view_size %d not supported", h->cfg.view_size);
+    }
+    MG_HIP(h, hipGetLastError());
+    return MG_OK;
+}
+
+void set_out(KParams &kp, const MgOut *out) {
+    kp.image = out ? out->image_dev : nullptr;
+    kp.direction = out ? out->direction_dev : nullptr;
+    kp.reward = out ? out->reward_dev : nullptr;
+    kp.terminated = out ? out->terminated_dev : nullptr;
+    kp.truncated = out ? out->truncated_dev : nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+const char *mg_last_error(MgHandle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mg_create(const MgConfig *cfg, MgHandle *out) {
+    if (!cfg || !out) return fail(nullptr, MG_EINVAL, "mg_create: null argument");
+    *out = nullptr;
+    const MgConfig &c = *cfg;
+    if (c.kind < 0 || c.kind > MG_KIND_LOCKEDHALLWAY) return fail(nullptr, MG_EINVAL, "unknown kind %d", c.kind);
+    if (c.width < 3 || c.height < 3 || c.width > 255 || c.height > 255 || c.width * c.height > 4096)
+        return fail(nullptr, MG_EINVAL, "grid %dx%d not supported (3..255 per side, at most 4096 cells)", c.width,
+                    c.height);
+    if (c.num_agents < 1 || c.num_agents > 64)
+        return fail(nullptr, MG_EINVAL, "num_agents %d not supported (1..64)", c.num_agents);
+    if (c.view_size != 3 && c.view_size != 5 && c.view_size != 7)
+        return fail(nullptr, MG_EINVAL, "view_size %d not supported (3, 5 or 7)", c.view_size);
+    if (c.max_steps < 1) return fail(nullptr, MG_EINVAL, "max_steps must be positive");
+    if (c.num_envs < 1) return fail(nullptr, MG_EINVAL, "num_envs must be positive");
+    if (c.autoreset < 0 || c.autoreset > MG_AUTORESET_NEXT_STEP)
+        return fail(nullptr, MG_EINVAL, "unknown autoreset mode %d", c.autoreset);
+    if (c.kind == MG_KIND_LOCKEDHALLWAY && (c.num_rooms < 1 || c.num_rooms > 6))
+        return fail(nullptr, MG_EINVAL, "LockedHallway needs 1..6 rooms (one door colour each), got %d", c.num_rooms);
+
+    MgEnv *h = new (std::nothrow) MgEnv();
+    if (!h) return fail(nullptr, MG_EINVAL, "out of host memory");
+    h->cfg = c;
+    KParams &kp = h->kp;
+    kp.kind = c.kind; kp.W = c.width; kp.H = c.height; kp.A = c.num_agents; kp.max_steps = c.max_steps;
+    kp.overlap = c.allow_agent_overlap != 0; kp.joint = c.joint_reward != 0;
+    kp.succ_any = c.success_any != 0; kp.fail_any = c.failure_any != 0;
+    kp.num_rooms = c.num_rooms; kp.autoreset = c.autoreset;
+    kp.E = c.num_envs;
+    kp.HS = 16 + 8 * round_up(c.num_agents, 2);
+    kp.GS = round_up(2 * c.width * c.height, 16);
+    kp.env_offset = static_cast<uint32_t>(c.env_id_offset);
+    kp.seed = c.seed;
+
+    // tile size: as many environments as give at most 64 agent lanes and fit a modest LDS budget
+    const int img = 3 * c.view_size * c.view_size;
+    int ne = 64 / c.num_agents;
+    auto lds_for = [&](int n) {
+        const int np = n * c.num_agents;
+        int o = 0;
+        auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
+        kp.o_hdr = take(n * kp.HS);
+        kp.o_grid = take(n * kp.GS);
+        kp.o_img = take(np * img + 32);
+        kp.o_act = take(np);
+        kp.o_ord = take(np);
+        kp.o_tout = take(np);
+        kp.o_oterm = take(np);
+        kp.o_flag = take(2 * n);
+        kp.o_dirty = take(2 * np);
+        kp.o_rew = take(8 * np);
+        return o;
+    };
+    while (ne > 1 && lds_for(ne) > 40 * 1024) --ne;
+    h->lds_bytes = static_cast<size_t>(lds_for(ne));
+    if (h->lds_bytes > 64 * 1024) {
+        delete h;
+        return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", h->lds_bytes);
+    }
+    kp.NE = ne;
+    h->num_tiles = (c.num_envs + ne - 1) / ne;
+
+    hipError_t e = hipSetDevice(c.device);
+    if (e == hipSuccess) e = hipMalloc(&h->hdr, static_cast<size_t>(c.num_envs) * kp.HS);
+    if (e == hipSuccess) e = hipMalloc(&h->grid, static_cast<size_t>(c.num_envs) * kp.GS);
+    if (e == hipSuccess) e = hipMalloc(&h->stats, 64 * MG_NUM_STATS * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMemset(h->hdr, 0, static_cast<size_t>(c.num_envs) * kp.HS);
+    if (e == hipSuccess) e = hipMemset(h->grid, 0, static_cast<size_t>(c.num_envs) * kp.GS);
+    if (e == hipSuccess) e = hipMemset(h->stats, 0, 64 * MG_NUM_STATS * sizeof(int64_t));
+    if (e != hipSuccess) {
+        fail(nullptr, MG_EHIP, "mg_create: %s", hipGetErrorString(e));
+        mg_destroy(h);
+        return MG_EHIP;
+    }
+    kp.hdr = h->hdr; kp.grid = h->grid; kp.stats = h->stats;
+    *out = h;
+    return MG_OK;
+}
+
+int mg_destroy(MgHandle h) {
+    if (!h) return MG_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->hdr) (void)hipFree(h->hdr);
+    if (h->grid) (void)hipFree(h->grid);
+    if (h->pool_hdr) (void)hipFree(h->pool_hdr);
+    if (h->pool_grid) (void)hipFree(h->pool_grid);
+    if (h->stats) (void)hipFree(h->stats);
+    delete h;
+    return MG_OK;
+}
+
+int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, const uint8_t *meta, int32_t n) {
+    if (!h) return MG_EINVAL;
+    if (!grids || !agents || n < 1) return fail(h, MG_EINVAL, "mg_upload_layouts: null pointer or n < 1");
+    const KParams &kp = h->kp;
+    const int cells = kp.W * kp.H, A = kp.A;
+    std::vector<uint8_t> ph(static_cast<size_t>(n) * kp.HS, 0), pg(static_cast<size_t>(n) * kp.GS, 0);
+    for (int l = 0; l < n; ++l) {
+        uint8_t *hd = ph.data() + static_cast<size_t>(l) * kp.HS;
+        uint16_t *gd = reinterpret_cast<uint16_t *>(pg.data() + static_cast<size_t>(l) * kp.GS);
+        for (int c = 0; c < cells; ++c) {
+            const uint8_t *s = grids + (static_cast<size_t>(l) * cells + c) * 3;
+            if (s[0] > 15 || s[1] > 127 || s[2] > 15)
+                return fail(h, MG_EINVAL, "layout %d cell %d = (%d,%d,%d) exceeds type<16, color<128, state<16", l, c,
+                            s[0], s[1], s[2]);
+            const uint32_t opaque = (s[0] == T_WALL) | ((s[0] == T_DOOR) & (s[2] != S_OPEN));
+            gd[c] = static_cast<uint16_t>(s[0] | (s[2] << 4) | (s[1] << 8) | (opaque << 15));
+        }
+        if (meta) memcpy(hd + H_META, meta + static_cast<size_t>(l) * 4, 4);
+        const uint8_t *ar = agents + static_cast<size_t>(l) * A * 8;
+        for (int k = 0; k < A; ++k) {
+            if (ar[8 * k + R_X] >= kp.W || ar[8 * k + R_Y] >= kp.H || ar[8 * k + R_DIR] > 3)
+                return fail(h, MG_EINVAL, "layout %d agent %d at (%d,%d) dir %d is outside the grid", l, k,
+                            ar[8 * k + R_X], ar[8 * k + R_Y], ar[8 * k + R_DIR]);
+            if (ar[8 * k + R_CT] > 15 || ar[8 * k + R_CC] > 127 || ar[8 * k + R_CS] > 15 || ar[8 * k + R_COLOR] > 127)
+                return fail(h, MG_EINVAL, "layout %d agent %d carries an out-of-range encoding", l, k);
+        }
+        memcpy(hd + H_ROWS, ar, static_cast<size_t>(A) * 8);
+        if (kp.kind == MG_KIND_REDBLUEDOORS && meta) {
+            const uint8_t *m = meta + static_cast<size_t>(l) * 4;
+            if (m[0] >= kp.W || m[2] >= kp.W || m[1] >= kp.H || m[3] >= kp.H)
+                return fail(h, MG_EINVAL, "layout %d door position outside the grid", l);
+        }
+    }
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    MG_HIP(h, hipDeviceSynchronize());
+    if (h->pool_hdr) { (void)hipFree(h->pool_hdr); h->pool_hdr = nullptr; }
+    if (h->pool_grid) { (void)hipFree(h->pool_grid); h->pool_grid = nullptr; }
+    MG_HIP(h, hipMalloc(&h->pool_hdr, ph.size()));
+    MG_HIP(h, hipMalloc(&h->pool_grid, pg.size()));
+    MG_HIP(h, hipMemcpy(h->pool_hdr, ph.data(), ph.size(), hipMemcpyHostToDevice));
+    MG_HIP(h, hipMemcpy(h->pool_grid, pg.data(), pg.size(), hipMemcpyHostToDevice));
+    h->num_layouts = n;
+    h->kp.pool_hdr = h->pool_hdr;
+    h->kp.pool_grid = h->pool_grid;
+    h->kp.num_layouts = n;
+    return MG_OK;
+}
+
+int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev, const MgOut *out, void *stream) {
+    if (!h) return MG_EINVAL;
+    if (h->num_layouts < 1) return fail(h, MG_ESTATE, "mg_reset: no layouts uploaded");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    KParams kp = h->kp;
+    kp.mode = MODE_RESET;
+    kp.layout_idx = layout_idx_dev;
+    kp.mask = mask_dev;
+    kp.serial = h->reset_serial;  // 0: first reset, episode counters start at 0
+    set_out(kp, out);
+    const int rc = launch_tile(h, kp, static_cast<hipStream_t>(stream));
+    if (rc != MG_OK) return rc;
+    h->reset_serial++;
+    h->reset_done = true;
+    return MG_OK;
+}
+
+int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out, void *stream) {
+    if (!h) return MG_EINVAL;
+    if (!actions_dev) return fail(h, MG_EINVAL, "mg_step: actions_dev is null");
+    if (!h->reset_done) return fail(h, MG_ESTATE, "mg_step: call mg_reset (or mg_set_state) first");
+    if (h->cfg.autoreset != MG_AUTORESET_NONE && h->num_layouts < 1)
+        return fail(h, MG_ESTATE, "mg_step: autoreset needs uploaded layouts");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    KParams kp = h->kp;
+    kp.mode = MODE_STEP;
+    kp.actions = actions_dev;
+    kp.order = order_dev;
+    kp.serial = h->step_serial;
+    set_out(kp, out);
+    const int rc = launch_tile(h, kp, static_cast<hipStream_t>(stream));
+    if (rc != MG_OK) return rc;
+    h->step_serial++;
+    h->launches++;
+    return MG_OK;
+}
+
+int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
+    if (!h) return MG_EINVAL;
+    if (!h->reset_done) return fail(h, MG_ESTATE, "mg_gen_obs: call mg_reset (or mg_set_state) first");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    KParams kp = h->kp;
+    kp.mode = MODE_OBS;
+    set_out(kp, out);
+    return launch_tile(h, kp, static_cast<hipStream_t>(stream));
+}
+
+int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *meta_dev, int32_t *steps_dev,
+                 uint8_t *flags_dev, void *stream) {
+    if (!h) return MG_EINVAL;
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W * h->kp.H;
+    const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 65535));
+    hipLaunchKernelGGL(mg_get_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
+                       grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);
+    MG_HIP(h, hipGetLastError());
+    return MG_OK;
+}
+
+int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev, const uint8_t *meta_dev,
+                 const int32_t *steps_dev, const uint8_t *flags_dev, void *stream) {
+    if (!h) return MG_EINVAL;
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W * h->kp.H;
+    const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 65535));
+    hipLaunchKernelGGL(mg_set_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
+                       grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);
+    MG_HIP(h, hipGetLastError());
+    h->reset_done = true;
+    return MG_OK;
+}
+
+int mg_stats(MgHandle h, int64_t *stats_dev, void *stream) {
+    if (!h) return MG_EINVAL;
+    if (!stats_dev) return fail(h, MG_EINVAL, "mg_stats: stats_dev is null");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(mg_stats_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), h->stats, stats_dev,
+                       h->launches);
+    MG_HIP(h, hipGetLastError());
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+/*
+ * Plain-C CPU restatement of the reference MultiGridEnv.step / gen_obs path,
+ * batched over independent environments.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE: the checker the HIP path is compared with
+ * at sizes where the Python restatement (oracle/pyref.py) would take minutes,
+ * and the compiled CPU baseline bench.py reports next to the GPU figure.
+ * Nothing under multigrid_amd/ links or loads it.
+ *
+ * Parity status: PINNED - tests/test_oracle_golden.py replays every trajectory
+ * recorded from the unmodified reference (the .npz files under tests/golden) through this
+ * library bit for bit (rewards compared as IEEE doubles).
+ *
+ * Arrays (E environments, reference layouts kept as they are):
+ *   grid    uint8 [E][W][H][3]   grid.state, x-major      (multigrid/core/grid.py:53)
+ *   agents  uint8 [E][A][8]      x y dir terminated carry_type carry_color carry_state color
+ *                                                          (multigrid/core/agent.py:266-275)
+ *   meta    uint8 [E][4]         RedBlueDoors: red_x red_y blue_x blue_y
+ *   steps   int32 [E]            step_count                (multigrid/base.py:350,395)
+ *   flags   uint8 [E]            bits 0-5: LockedHallway doors already rewarded, by door
+ *                                colour (locked_hallway.py:190,204-205); bit 7: the blue
+ *                                Door object was re-closed after a failure while its grid
+ *                                cell still reads open (redbluedoors.py:185)
+ */
+#include <stdint.h>
+#include <string.h>
+
+enum { T_UNSEEN, T_EMPTY, T_WALL, T_FLOOR, T_DOOR, T_KEY, T_BALL, T_BOX, T_GOAL, T_LAVA, T_AGENT };
+enum { S_OPEN, S_CLOSED, S_LOCKED };
+enum { A_LEFT, A_RIGHT, A_FORWARD, A_PICKUP, A_DROP, A_TOGGLE, A_DONE };
+enum { K_EMPTY, K_REDBLUEDOORS, K_BLOCKEDUNLOCKPICKUP, K_LOCKEDHALLWAY };
+enum { AX, AY, ADIR, ATERM, ACT, ACC, ACS, ACOLOR };
+#define FLAG_BLUE_STALE 0x80
+#define MAX_AGENTS 64
+#define MAX_VIEW 15
+
+typedef struct {
+    int32_t kind, width, height, num_agents, view_size, max_steps;
+    int32_t see_through_walls, allow_agent_overlap, joint_reward;
+    int32_t success_any, failure_any, num_rooms;
+} mgo_spec;
+
+/* DIR_TO_VEC, multigrid/core/constants.py:20-29 */
+static const int DX[4] = {1, 0, -1, 0};
+static const int DY[4] = {0, 1, 0, -1};
+
+/* ---- observation -------------------------------------------------------------- */
+
+/* see_behind, multigrid/utils/obs.py:44-61 */
+static int see_behind(const uint8_t *c) {
+    if (c[0] == T_WALL) return 0;
+    if (c[0] == T_DOOR && c[2] != S_OPEN) return 0;
+    return 1;
+}
+
+/* gen_obs_grid_encoding for one environment: multigrid/utils/obs.py:64-99,
+ * gen_obs_grid :127-203, get_view_exts :272-310, get_vis_mask :231-269 */
+static void obs_one(const mgo_spec *sp, const uint8_t *grid, const uint8_t *agents, uint8_t *image) {
+    const int W = sp->width, H = sp->height, A = sp->num_agents, V = sp->view_size;
+    for (int a = 0; a < A; ++a) {
+        const uint8_t *ag = agents + 8 * a;
+        uint8_t *img = image + (size_t)a * V * V * 3;
+        const int d = ag[ADIR];
+        int tx, ty; /* obs.py:294-308 */
+        if (d == 0)      { tx = ag[AX];             ty = ag[AY] - V / 2; }
+        else if (d == 1) { tx = ag[AX] - V / 2;     ty = ag[AY]; }
+        else if (d == 2) { tx = ag[AX] - V + 1;     ty = ag[AY] - V / 2; }
+        else             { tx = ag[AX] - V / 2;     ty = ag[AY] - V + 1; }
+        const int rot = (d + 1) % 4; /* obs.py:174 */
+        for (int i = 0; i < V; ++i)
+            for (int j = 0; j < V; ++j) {
+                const int x = tx + i, y = ty + j;
+                int ir, jr; /* obs.py:183-190 */
+                if (rot == 0)      { ir = i;         jr = j; }
+                else if (rot == 1) { ir = j;         jr = V - i - 1; }
+                else if (rot == 2) { ir = V - i - 1; jr = V - j - 1; }
+                else               { ir = V - j - 1; jr = i; }
+                uint8_t *o = img + (ir * V + jr) * 3;
+                if (x >= 0 && x < W && y >= 0 && y < H) { /* obs.py:193-194 */
+                    const uint8_t *c = grid + ((size_t)x * H + y) * 3;
+                    o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+                    if (A > 1) /* agent overlay, index order, later agents win: obs.py:157-165 */
+                        for (int k = 0; k < A; ++k) {
+                            const uint8_t *ak = agents + 8 * k;
+                            if (!ak[ATERM] && ak[AX] == x && ak[AY] == y) {
+                                o[0] = T_AGENT; o[1] = ak[ACOLOR]; o[2] = ak[ADIR];
+                            }
+                        }
+                } else { /* WALL_ENCODING, obs.py:13,196 */
+                    o[0] = T_WALL; o[1] = 5; o[2] = 0;
+                }
+            }
+        /* carried object shown on the agent's own cell: obs.py:201 */
+        uint8_t *self = img + ((V / 2) * V + (V - 1)) * 3;
+        self[0] = ag[ACT]; self[1] = ag[ACC]; self[2] = ag[ACS];
+
+        if (!sp->see_through_walls) { /* obs.py:89-97 */
+            uint8_t vis[MAX_VIEW][MAX_VIEW];
+            memset(vis, 0, sizeof vis);
+            vis[V / 2][V - 1] = 1; /* obs.py:249 */
+            for (int j = V - 1; j >= 0; --j) {
+                for (int i = 0; i < V - 1; ++i) /* forward pass, obs.py:254-259 */
+                    if (vis[i][j] && see_behind(img + (i * V + j) * 3)) {
+                        vis[i + 1][j] = 1;
+                        if (j > 0) { vis[i + 1][j - 1] = 1; vis[i][j - 1] = 1; }
+                    }
+                for (int i = V - 1; i > 0; --i) /* backward pass, obs.py:262-267 */
+                    if (vis[i][j] && see_behind(img + (i * V + j) * 3)) {
+                        vis[i - 1][j] = 1;
+                        if (j > 0) { vis[i - 1][j - 1] = 1; vis[i][j - 1] = 1; }
+                    }
+            }
+            for (int i = 0; i < V; ++i)
+                for (int j = 0; j < V; ++j)
+                    if (!vis[i][j]) { /* UNSEEN_ENCODING, obs.py:14 */
+                        uint8_t *o = img + (i * V + j) * 3;
+                        o[0] = 0; o[1] = 0; o[2] = 0;
+                    }
+        }
+    }
+}
+
+void mgo_gen_obs(const mgo_spec *sp, int64_t E, const uint8_t *grid, const uint8_t *agents, uint8_t *image) {
+    const size_t gs = (size_t)sp->width * sp->height * 3, as = (size_t)sp->num_agents * 8;
+    const size_t is = (size_t)sp->num_agents * sp->view_size * sp->view_size * 3;
+    for (int64_t e = 0; e < E; ++e) obs_one(sp, grid + e * gs, agents + e * as, image + e * is);
+}
+
+/* ---- step --------------------------------------------------------------------- */
+
+typedef struct {
+    const mgo_spec *sp;
+    uint8_t *grid, *agents;
+    const uint8_t *meta;
+    int32_t steps;
+    uint8_t flags;
+    double *reward;
+} env_t;
+
+static uint8_t *cell(env_t *e, int x, int y) { return e->grid + ((size_t)x * e->sp->height + y) * 3; }
+
+static int is_blue(const env_t *e, int x, int y) {
+    return e->sp->kind == K_REDBLUEDOORS && x == e->meta[2] && y == e->meta[3];
+}
+
+/* state of the world OBJECT at a cell; it differs from the grid cell only for the
+ * blue door re-closed at redbluedoors.py:185 without a grid.update */
+static int object_state(env_t *e, int x, int y) {
+    if ((e->flags & FLAG_BLUE_STALE) && is_blue(e, x, y)) return S_CLOSED;
+    return cell(e, x, y)[2];
+}
+
+/* base.py:485,512: every agent counts, terminated ones too */
+static int agent_at(const env_t *e, int x, int y) {
+    for (int k = 0; k < e->sp->num_agents; ++k)
+        if (e->agents[8 * k + AX] == x && e->agents[8 * k + AY] == y) return 1;
+    return 0;
+}
+
+/* base.py:655-659 */
+static double reward_now(const env_t *e) {
+    return 1 - 0.9 * ((double)e->steps / (double)e->sp->max_steps);
+}
+
+/* base.py:535-562; term_out == NULL stands for the empty dict passed at base.py:492 */
+static void on_success(env_t *e, int i, uint8_t *term_out) {
+    const int A = e->sp->num_agents;
+    if (e->sp->success_any) {
+        if (term_out)
+            for (int k = 0; k < A; ++k) { e->agents[8 * k + ATERM] = 1; term_out[k] = 1; }
+    } else {
+        e->agents[8 * i + ATERM] = 1;
+        if (term_out) term_out[i] = 1;
+    }
+    if (e->sp->joint_reward)
+        for (int k = 0; k < A; ++k) e->reward[k] = reward_now(e);
+    else
+        e->reward[i] = reward_now(e);
+}
+
+/* base.py:564-585 */
+static void on_failure(env_t *e, int i, uint8_t *term_out) {
+    const int A = e->sp->num_agents;
+    if (e->sp->failure_any) {
+        if (term_out)
+            for (int k = 0; k < A; ++k) { e->agents[8 * k + ATERM] = 1; term_out[k] = 1; }
+    } else {
+        e->agents[8 * i + ATERM] = 1;
+        if (term_out) term_out[i] = 1;
+    }
+}
+
+/* handle_actions, base.py:440-533 */
+static void handle_actions(env_t *e, const uint8_t *actions, const uint8_t *order) {
+    const mgo_spec *sp = e->sp;
+    for (int n = 0; n < sp->num_agents; ++n) {
+        const int i = order ? order[n] : n;
+        uint8_t *ag = e->agents + 8 * i;
+        if (ag[ATERM]) continue; /* base.py:467 */
+        const int act = actions[i];
+        if (act == A_LEFT) { ag[ADIR] = (uint8_t)((ag[ADIR] + 3) % 4); continue; }  /* :471-472 */
+        if (act == A_RIGHT) { ag[ADIR] = (uint8_t)((ag[ADIR] + 1) % 4); continue; } /* :475-476 */
+        if (act == A_DONE || act > A_DONE) continue;                                /* :527-528 */
+        const int fx = ag[AX] + DX[ag[ADIR]], fy = ag[AY] + DY[ag[ADIR]]; /* agent.py:153-160 */
+        if (fx < 0 || fx >= sp->width || fy < 0 || fy >= sp->height) continue; /* never true inside border walls */
+        uint8_t *c = cell(e, fx, fy);
+        const int t = c[0];
+        if (act == A_FORWARD) { /* base.py:479-494 */
+            const int can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
+                                    (t == T_DOOR && object_state(e, fx, fy) == S_OPEN);
+            if (!can_overlap) continue;
+            if (!sp->allow_agent_overlap && agent_at(e, fx, fy)) continue;
+            ag[AX] = (uint8_t)fx; ag[AY] = (uint8_t)fy;
+            if (t == T_GOAL) on_success(e, i, NULL);
+            if (t == T_LAVA) on_failure(e, i, NULL);
+        } else if (act == A_PICKUP) { /* base.py:497-504 */
+            if ((t == T_KEY || t == T_BALL || t == T_BOX) && ag[ACT] == T_EMPTY) {
+                ag[ACT] = c[0]; ag[ACC] = c[1]; ag[ACS] = c[2];
+                c[0] = T_EMPTY; c[1] = 0; c[2] = 0;
+            }
+        } else if (act == A_DROP) { /* base.py:507-516 */
+            if (ag[ACT] != T_EMPTY && t == T_EMPTY && !agent_at(e, fx, fy)) {
+                c[0] = ag[ACT]; c[1] = ag[ACC]; c[2] = ag[ACS];
+                ag[ACT] = T_EMPTY; ag[ACC] = 0; ag[ACS] = 0;
+            }
+        } else if (act == A_TOGGLE) { /* base.py:519-524 */
+            if (t == T_DOOR) { /* Door.toggle, world_object.py:456-472 */
+                const int s = object_state(e, fx, fy);
+                if (s == S_LOCKED) {
+                    if (ag[ACT] == T_KEY && ag[ACC] == c[1]) c[2] = S_OPEN;
+                } else {
+                    c[2] = (uint8_t)(s == S_OPEN ? S_CLOSED : S_OPEN);
+                    if (is_blue(e, fx, fy)) e->flags &= (uint8_t)~FLAG_BLUE_STALE;
+                }
+            } else if (t == T_BOX) { /* Box.toggle with no contents, world_object.py:653-659 */
+                c[0] = T_EMPTY; c[1] = 0; c[2] = 0;
+            }
+        }
+    }
+}
+
+static int popcount6(unsigned m) {
+    int n = 0;
+    for (int b = 0; b < 6; ++b) n += (m >> b) & 1;
+    return n;
+}
+
+/* MultiGridEnv.step (base.py:364-408) followed by the subclass hook */
+static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, const uint8_t *meta, int32_t *steps,
+                     uint8_t *flags, const uint8_t *actions, const uint8_t *order, uint8_t *image,
+                     uint8_t *direction, double *reward, uint8_t *terminated, uint8_t *truncated) {
+    const int A = sp->num_agents;
+    env_t e = {sp, grid, agents, meta, *steps + 1 /* base.py:395 */, *flags, reward};
+    for (int k = 0; k < A; ++k) reward[k] = 0; /* base.py:454 */
+    handle_actions(&e, actions, order);
+    obs_one(sp, grid, agents, image); /* base.py:399 */
+    for (int k = 0; k < A; ++k) {
+        direction[k] = agents[8 * k + ADIR];
+        terminated[k] = agents[8 * k + ATERM];            /* base.py:400 */
+        truncated[k] = (uint8_t)(e.steps >= sp->max_steps); /* base.py:401-402 */
+    }
+    if (sp->kind == K_REDBLUEDOORS) { /* redbluedoors.py:176-185 */
+        for (int i = 0; i < A; ++i) {
+            if (actions[i] != A_TOGGLE) continue;
+            const uint8_t *ag = agents + 8 * i;
+            const int fx = ag[AX] + DX[ag[ADIR]], fy = ag[AY] + DY[ag[ADIR]];
+            if (!is_blue(&e, fx, fy) || cell(&e, fx, fy)[0] != T_DOOR) continue;
+            if (object_state(&e, fx, fy) != S_OPEN) continue;
+            if (cell(&e, meta[0], meta[1])[2] == S_OPEN) {
+                on_success(&e, i, terminated);
+            } else {
+                on_failure(&e, i, terminated);
+                e.flags |= FLAG_BLUE_STALE; /* object closed again, grid cell not refreshed */
+            }
+        }
+    } else if (sp->kind == K_BLOCKEDUNLOCKPICKUP) { /* blockedunlockpickup.py:165-167 */
+        for (int i = 0; i < A; ++i)
+            if (agents[8 * i + ACT] == T_BOX) on_success(&e, i, terminated);
+    } else if (sp->kind == K_LOCKEDHALLWAY) { /* locked_hallway.py:200-215 */
+        for (int i = 0; i < A; ++i) {
+            if (actions[i] != A_TOGGLE) continue;
+            const uint8_t *ag = agents + 8 * i;
+            const int fx = ag[AX] + DX[ag[ADIR]], fy = ag[AY] + DY[ag[ADIR]];
+            if (fx < 0 || fx >= sp->width || fy < 0 || fy >= sp->height) continue;
+            const uint8_t *c = cell(&e, fx, fy);
+            if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;
+            const unsigned bit = 1u << (c[1] & 7);
+            if (e.flags & bit) continue;
+            e.flags |= (uint8_t)bit;
+            if (sp->joint_reward)
+                for (int k = 0; k < A; ++k) reward[k] += reward_now(&e);
+            else
+                reward[i] += reward_now(&e);
+        }
+        if (popcount6(e.flags & 0x3F) == sp->num_rooms)
+            for (int k = 0; k < A; ++k) terminated[k] = 1;
+    }
+    *steps = e.steps;
+    *flags = e.flags;
+}
+
+void mgo_step(const mgo_spec *sp, int64_t E, uint8_t *grid, uint8_t *agents, const uint8_t *meta,
+              int32_t *steps, uint8_t *flags, const uint8_t *actions, const uint8_t *order,
+              uint8_t *image, uint8_t *direction, double *reward, uint8_t *terminated,
+              uint8_t *truncated) {
+    const int A = sp->num_agents, V = sp->view_size;
+    const size_t gs = (size_t)sp->width * sp->height * 3, as = (size_t)A * 8, is = (size_t)A * V * V * 3;
+    for (int64_t e = 0; e < E; ++e)
+        step_one(sp, grid + e * gs, agents + e * as, meta + e * 4, steps + e, flags + e,
+                 actions + e * A, order ? order + e * A : NULL, image + e * is, direction + e * A,
+                 reward + e * A, terminated + e * A, truncated + e * A);
+}
+
+int mgo_abi_version(void) { return 1; }

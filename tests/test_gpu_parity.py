@@ -1,0 +1,44 @@
+"""HIP path vs the golden trajectories recorded from the reference, through the C ABI."""
+import numpy as np
+import pytest
+
+from golden_util import group_names, load_group
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(spec, n, **kw):
+    from multigrid_amd.batched import BatchedMultiGrid
+    return BatchedMultiGrid(spec, n, device=0, **kw)
+
+
+@pytest.mark.parametrize("name", group_names())
+def test_hip_replays_reference(name):
+    import torch
+
+    spec, d = load_group(name)
+    n = len(d["length"])
+    env = _mk(spec, n)
+    env.upload_layouts(d["layout_grid"], d["layout_agents"], d["layout_meta"])
+    out = env.reset(layout_idx=np.arange(n))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.image.cpu().numpy(), d["reset_image"], err_msg=f"{name} reset obs")
+    np.testing.assert_array_equal(out.direction.cpu().numpy(), d["layout_agents"][:, :, 2])
+    for t in range(int(d["length"].max())):
+        live = d["length"] > t
+        out = env.step(d["actions"][:, t], d["order"][:, t])
+        st = env.get_state()
+        where = f"{name} step {t}"
+        np.testing.assert_array_equal(out.image.cpu().numpy()[live], d["image"][live, t], err_msg=where + " image")
+        np.testing.assert_array_equal(out.direction.cpu().numpy()[live], d["direction"][live, t],
+                                      err_msg=where + " direction")
+        np.testing.assert_allclose(out.reward.cpu().numpy()[live], d["reward"][live, t], rtol=0, atol=1e-6,
+                                   err_msg=where + " reward")  # reference rewards are float64
+        np.testing.assert_array_equal(out.terminated.cpu().numpy()[live].astype(bool), d["terminated"][live, t],
+                                      err_msg=where + " terminated")
+        np.testing.assert_array_equal(out.truncated.cpu().numpy()[live].astype(bool), d["truncated"][live, t],
+                                      err_msg=where + " truncated")
+        np.testing.assert_array_equal(st["grid"].cpu().numpy()[live], d["post_grid"][live, t], err_msg=where + " grid")
+        np.testing.assert_array_equal(st["agents"].cpu().numpy()[live], d["post_agents"][live, t],
+                                      err_msg=where + " agents")
+    env.close()

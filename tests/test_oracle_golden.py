@@ -36,3 +36,26 @@ def test_pyref_replays_reference(name, fast_obs):
                                           err_msg=where + " truncated")
             np.testing.assert_array_equal(env.grid, d["post_grid"][n, t], err_msg=where + " grid")
             np.testing.assert_array_equal(env.agents, d["post_agents"][n, t], err_msg=where + " agents")
+
+
+@pytest.mark.parametrize("name", group_names())
+def test_c_oracle_replays_reference(name):
+    """oracle/mg_oracle.c: all trajectories of a group stepped as one batch."""
+    from oracle.coracle import BatchOracle
+
+    spec, d = load_group(name)
+    n = len(d["length"])
+    bo = BatchOracle(spec, n)
+    bo.load(np.arange(n), d["layout_grid"], d["layout_agents"], d["layout_meta"])
+    np.testing.assert_array_equal(bo.gen_obs(), d["reset_image"], err_msg=f"{name} reset obs")
+    for t in range(int(d["length"].max())):
+        live = d["length"] > t
+        img, direction, rew, term, trunc = bo.step(d["actions"][:, t], d["order"][:, t])
+        where = f"{name} step {t}"
+        np.testing.assert_array_equal(img[live], d["image"][live, t], err_msg=where + " image")
+        np.testing.assert_array_equal(direction[live], d["direction"][live, t], err_msg=where + " dir")
+        np.testing.assert_array_equal(rew[live], d["reward"][live, t], err_msg=where + " reward")
+        np.testing.assert_array_equal(term[live].astype(bool), d["terminated"][live, t], err_msg=where + " term")
+        np.testing.assert_array_equal(trunc[live].astype(bool), d["truncated"][live, t], err_msg=where + " trunc")
+        np.testing.assert_array_equal(bo.grid[live], d["post_grid"][live, t], err_msg=where + " grid")
+        np.testing.assert_array_equal(bo.agents[live], d["post_agents"][live, t], err_msg=where + " agents")
