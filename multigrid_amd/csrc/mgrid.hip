@@ -59,7 +59,7 @@ struct KParams {
     int E, NE, HS, GS, num_layouts;
     uint32_t env_offset;
     uint64_t seed;
-    uint32_t serial;  // launch counter, keys the on-device order generator
+    uint32_t serial;  // reset launches so far (0: the first reset starts the episode counters)
     int mode;
     // state
     uint8_t *hdr;
@@ -173,10 +173,12 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     const bool rbd = p.kind == MG_KIND_REDBLUEDOORS;
 
     if (p.order == nullptr) {
-        // uniform random permutation, keyed by (seed, launch, global environment index);
+        // uniform random permutation, keyed by (seed, global environment index, episode, step) so
+        // that it does not depend on how launches are issued (eager, graph replay, sharding);
         // stands in for np_random.random(A).argsort() of base.py:457-461
-        uint64_t st = mix64(p.seed ^ (static_cast<uint64_t>(p.serial) << 32) ^
-                            (static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env)));
+        const uint64_t gid = static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env);
+        const uint64_t epi = *reinterpret_cast<const uint32_t *>(ev.h + H_EPISODE);
+        uint64_t st = mix64(mix64(p.seed ^ (gid << 20)) ^ (epi << 32) ^ static_cast<uint64_t>(step));
         for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
         for (int k = A - 1; k > 0; --k) {
             st = mix64(st + 0x9E3779B97F4A7C15ull);

@@ -1,0 +1,286 @@
+"""HIP path vs the C oracle on large, multi-tile batches: resets, auto-reset modes, on-device agent
+order, odd alignments, statistics.  Everything goes through the C ABI (multigrid_amd.batched)."""
+import numpy as np
+import pytest
+
+from multigrid_amd import envs, layouts
+
+pytestmark = pytest.mark.gpu
+
+BIASED = np.array([0.12, 0.12, 0.36, 0.12, 0.08, 0.18, 0.02])
+LAYOUT_STRIDE = 7919
+
+CASES = {
+    "cfg1": ("MultiGrid-Empty-8x8-v0", 2, dict(max_steps=48)),
+    "cfg2": ("MultiGrid-RedBlueDoors-8x8-v0", 2, dict(max_steps=40)),
+    "cfg3": ("MultiGrid-BlockedUnlockPickup-v0", 2, dict(max_steps=60)),
+    "cfg4": ("MultiGrid-LockedHallway-4Rooms-v0", 4, dict(max_steps=50)),
+    "cfg5": ("MultiGrid-Empty-16x16-v0", 8, dict(max_steps=64)),
+    "cfg5_nooverlap": ("MultiGrid-Empty-16x16-v0", 8, dict(max_steps=64, allow_agent_overlap=False)),
+    "odd3": ("MultiGrid-Empty-Random-6x6-v0", 3, dict(max_steps=30, success_termination_mode="all")),
+    "odd5": ("MultiGrid-LockedHallway-2Rooms-v0", 5, dict(max_steps=30)),
+    "single": ("MultiGrid-BlockedUnlockPickup-v0", 1, dict(max_steps=30)),
+}
+
+
+BASELINE = {
+    "cfg2": ("MultiGrid-RedBlueDoors-8x8-v0", 2, {}),
+    "cfg3": ("MultiGrid-BlockedUnlockPickup-v0", 2, {}),
+    "cfg4": ("MultiGrid-LockedHallway-4Rooms-v0", 4, {}),
+    "cfg5": ("MultiGrid-Empty-16x16-v0", 8, {}),
+}
+
+
+def make(case, num_envs, n_layouts=64, table=None, **kw):
+    from multigrid_amd.batched import BatchedMultiGrid
+    from oracle.coracle import BatchOracle
+
+    name, agents, extra = (table or CASES)[case]
+    spec, gen = envs.make_spec(name, num_agents=agents, **extra)
+    pool = layouts.make_pool(gen, n_layouts, seed0=7)
+    env = BatchedMultiGrid(spec, num_envs, device=0, **kw)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    return spec, pool, env, BatchOracle(spec, num_envs)
+
+
+def compare(out, ora_out, where, image=True):
+    import torch
+    torch.cuda.synchronize()
+    img, direction, rew, term, trunc = ora_out
+    if image:
+        np.testing.assert_array_equal(out.image.cpu().numpy(), img, err_msg=where + " image")
+        np.testing.assert_array_equal(out.direction.cpu().numpy(), direction, err_msg=where + " direction")
+    np.testing.assert_allclose(out.reward.cpu().numpy(), rew, rtol=0, atol=1e-6, err_msg=where + " reward")
+    np.testing.assert_array_equal(out.terminated.cpu().numpy(), term, err_msg=where + " terminated")
+    np.testing.assert_array_equal(out.truncated.cpu().numpy(), trunc, err_msg=where + " truncated")
+
+
+def compare_state(env, ora, where):
+    st = env.get_state()
+    np.testing.assert_array_equal(st["grid"].cpu().numpy(), ora.grid, err_msg=where + " grid")
+    np.testing.assert_array_equal(st["agents"].cpu().numpy(), ora.agents, err_msg=where + " agents")
+    np.testing.assert_array_equal(st["steps"].cpu().numpy(), ora.steps, err_msg=where + " steps")
+    np.testing.assert_array_equal(st["flags"].cpu().numpy(), ora.flags, err_msg=where + " flags")
+    np.testing.assert_array_equal(st["meta"].cpu().numpy(), ora.meta, err_msg=where + " meta")
+
+
+def rand_inputs(rng, e, a):
+    actions = rng.choice(7, size=(e, a), p=BIASED).astype(np.uint8)
+    order = np.argsort(rng.random((e, a)), axis=1).astype(np.uint8)
+    return actions, order
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_manual_reset_loop(case):
+    """Reference usage: step until done, then reset() that environment (here: masked mg_reset)."""
+    e = 3000 if case != "single" else 1500
+    spec, pool, env, ora = make(case, e)
+    a = spec["num_agents"]
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, len(pool[0]), size=e)
+    out = env.reset(layout_idx=idx)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    np.testing.assert_array_equal(out.image.cpu().numpy(), ora.gen_obs(), err_msg="reset image")
+    for t in range(70):
+        actions, order = rand_inputs(rng, e, a)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        compare(out, res, f"{case} step {t}")
+        if t % 10 == 9:
+            compare_state(env, ora, f"{case} step {t}")
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            new = rng.integers(0, len(pool[0]), size=e)
+            ora.load(ids, pool[0][new[ids]], pool[1][new[ids]], pool[2][new[ids]])
+            expect_img = out.image.cpu().numpy().copy()
+            expect_img[ids] = ora.gen_obs()[ids]
+            out = env.reset(layout_idx=new, mask=done.astype(np.uint8))
+            # only the reset environments' observations may change
+            np.testing.assert_array_equal(out.image.cpu().numpy(), expect_img, err_msg=f"{case} masked reset {t}")
+    compare_state(env, ora, f"{case} final")
+    env.close()
+
+
+def expected_layout(env_ids, episode, n_layouts, offset=0):
+    return (offset + env_ids + LAYOUT_STRIDE * episode) % n_layouts
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "odd3"])
+def test_autoreset_modes(case, mode):
+    e, offset = 2500, 1000
+    spec, pool, env, ora = make(case, e, autoreset=mode, env_id_offset=offset)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(2)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    out = env.reset()
+    idx = expected_layout(ids_all, episode, n_l, offset)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    np.testing.assert_array_equal(out.image.cpu().numpy(), ora.gen_obs())
+    n_done = n_term = n_trunc = 0
+    len_sum = 0
+    rew_sum = 0.0
+    for t in range(90):
+        actions, order = rand_inputs(rng, e, a)
+        out = env.step(actions, order)
+        img, direction, rew, term, trunc = ora.step(actions, order)
+        img, direction = img.copy(), direction.copy()
+        done = term.all(axis=1) | trunc.all(axis=1)
+        rew_sum += np.floor(rew.sum(axis=1) * 2 ** 24).sum() / 2 ** 24
+        if done.any():
+            ids = np.nonzero(done)[0]
+            n_done += len(ids)
+            n_term += int(term.all(axis=1)[ids].sum())
+            n_trunc += int((~term.all(axis=1))[ids].sum())
+            len_sum += int(ora.steps[ids].sum())
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l, offset)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+            if mode == 1:  # the caller sees the next episode's first observation
+                fresh = ora.gen_obs()
+                img[ids] = fresh[ids]
+                direction[ids] = ora.agents[ids, :, 2]
+        compare(out, (img, direction, rew, term, trunc), f"{case} mode {mode} step {t}")
+        if t % 15 == 14:
+            compare_state(env, ora, f"{case} mode {mode} step {t}")
+    assert n_done > 0
+    st = env.stats().cpu().numpy()
+    assert st[0] == n_done and st[1] == len_sum and st[2] == n_term and st[3] == n_trunc and st[5] == 90
+    assert abs(st[4] / 2 ** 24 - rew_sum) < 1e-3 * max(1.0, rew_sum)
+    env.close()
+
+
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def mix64(z):
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def device_order(seed, gid, episode, step, a):
+    """The documented on-device permutation: Fisher-Yates driven by a splitmix64 stream keyed by
+    (seed, global environment index, episode, step)."""
+    with np.errstate(over="ignore"):
+        gid, episode, step = (np.asarray(x).astype(np.uint64) for x in (gid, episode, step))
+        st = mix64(mix64(np.uint64(seed) ^ (gid << np.uint64(20))) ^ (episode << np.uint64(32)) ^ step)
+        order = np.tile(np.arange(a, dtype=np.uint8), (len(gid), 1))
+        rows = np.arange(len(gid))
+        for k in range(a - 1, 0, -1):
+            st = mix64(st + np.uint64(0x9E3779B97F4A7C15))
+            j = (((st >> np.uint64(32)) * np.uint64(k + 1)) >> np.uint64(32)).astype(np.int64)
+            tmp = order[rows, k].copy()
+            order[rows, k] = order[rows, j]
+            order[rows, j] = tmp
+    return order
+
+
+@pytest.mark.parametrize("case", ["cfg4", "cfg5_nooverlap"])
+def test_on_device_agent_order(case):
+    e, offset, seed = 2048, 77, 99
+    spec, pool, env, ora = make(case, e, autoreset=1, env_id_offset=offset, seed=seed)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(3)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    env.reset()
+    idx = expected_layout(ids_all, episode, n_l, offset)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    seen = set()
+    for t in range(80):
+        actions, _ = rand_inputs(rng, e, a)
+        order = device_order(seed, offset + ids_all, episode, ora.steps + 1, a)
+        seen.update(map(bytes, order[:64]))
+        out = env.step(actions, None)
+        img, direction, rew, term, trunc = ora.step(actions, order)
+        img, direction = img.copy(), direction.copy()
+        done = term.all(axis=1) | trunc.all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l, offset)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+            img[ids] = ora.gen_obs()[ids]
+            direction[ids] = ora.agents[ids, :, 2]
+        compare(out, (img, direction, rew, term, trunc), f"{case} device order step {t}")
+    assert len(seen) > 20  # the permutations do vary
+    env.close()
+
+
+def test_gen_obs_entry_point():
+    spec, pool, env, ora = make("cfg4", 777)
+    idx = np.arange(777) % len(pool[0])
+    env.reset(layout_idx=idx)
+    ora.load(np.arange(777), pool[0][idx], pool[1][idx], pool[2][idx])
+    rng = np.random.default_rng(4)
+    for t in range(5):
+        actions, order = rand_inputs(rng, 777, spec["num_agents"])
+        env.step(actions, order)
+        ora.step(actions, order)
+    import torch
+    from multigrid_amd.batched import StepOutput
+    o = StepOutput(image=torch.full_like(env.out.image, 255), direction=torch.full_like(env.out.direction, 255),
+                   reward=env.out.reward, terminated=env.out.terminated, truncated=env.out.truncated)
+    env.gen_obs(out=o)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(o.image.cpu().numpy(), ora.gen_obs())
+    np.testing.assert_array_equal(o.direction.cpu().numpy(), ora.agents[:, :, 2])
+    env.close()
+
+
+def test_set_state_roundtrip_and_errors():
+    from multigrid_amd._lib import MgError
+    spec, pool, env, ora = make("cfg3", 500)
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, len(pool[0]), 500)
+    env.set_state(grid=pool[0][idx], agents=pool[1][idx], meta=pool[2][idx],
+                  steps=np.full(500, 7, np.int32), flags=np.zeros(500, np.uint8))
+    ora.load(np.arange(500), pool[0][idx], pool[1][idx], pool[2][idx])
+    ora.steps[:] = 7
+    compare_state(env, ora, "after set_state")
+    actions, order = rand_inputs(rng, 500, 2)
+    compare(env.step(actions, order), ora.step(actions, order), "step after set_state")
+    with pytest.raises(ValueError):
+        env.step(np.zeros((3, 2), np.uint8))
+    bad = pool[0][:4].copy()
+    bad[0, 0, 0, 0] = 99
+    with pytest.raises(MgError):
+        env.upload_layouts(bad, pool[1][:4], pool[2][:4])
+    env.close()
+
+
+@pytest.mark.parametrize("case,e", [("cfg2", 4096), ("cfg3", 65536), ("cfg4", 65536), ("cfg5", 131072)])
+def test_baseline_sizes(case, e):
+    """Full BASELINE batch sizes (per GPU), auto-reset on, checked against the C oracle."""
+    offset = 0
+    spec, pool, env, ora = make(case, e, table=BASELINE, autoreset=1)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(6)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    env.reset()
+    idx = expected_layout(ids_all, episode, n_l, offset)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    # start episodes at scattered step counts so that truncations and resets occur immediately
+    steps0 = rng.integers(0, spec["max_steps"], size=e).astype(np.int32)
+    env.set_state(steps=steps0)
+    ora.steps[:] = steps0
+    for t in range(12):
+        actions, order = rand_inputs(rng, e, a)
+        out = env.step(actions, order)
+        img, direction, rew, term, trunc = ora.step(actions, order)
+        img, direction = img.copy(), direction.copy()
+        done = term.all(axis=1) | trunc.all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l, offset)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+            img[ids] = ora.gen_obs()[ids]
+            direction[ids] = ora.agents[ids, :, 2]
+        compare(out, (img, direction, rew, term, trunc), f"{case} E={e} step {t}")
+    compare_state(env, ora, f"{case} E={e} final")
+    env.close()

@@ -1,0 +1,47 @@
+"""Host-side layout generators reproduce the reference's reset() layouts for the same generators."""
+import numpy as np
+import pytest
+
+from golden_util import load_layout_fixture
+from multigrid_amd import envs
+
+CASES = ["MultiGrid-Empty-8x8-v0", "MultiGrid-RedBlueDoors-8x8-v0", "MultiGrid-BlockedUnlockPickup-v0",
+         "MultiGrid-LockedHallway-4Rooms-v0", "MultiGrid-LockedHallway-2Rooms-v0",
+         "MultiGrid-LockedHallway-6Rooms-v0", "MultiGrid-Empty-16x16-v0", "MultiGrid-RedBlueDoors-6x6-v0",
+         "MultiGrid-Empty-Random-6x6-v0"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_layout_generator_matches_reference(name):
+    fx = load_layout_fixture()
+    key = name.replace("MultiGrid-", "").replace("-", "_")
+    a = int(fx[key + "__num_agents"])
+    spec, gen = envs.make_spec(name, num_agents=a)
+    for seed in range(fx[key + "__grid"].shape[0]):
+        # the fixture generator seeds RandomMixin with `seed` and calls reset(seed=seed + 100)
+        grid, agents, meta, mission = gen(mixin_rng=np.random.default_rng(seed),
+                                          env_rng=np.random.default_rng(seed + 100))
+        np.testing.assert_array_equal(grid, fx[key + "__grid"][seed], err_msg=f"{name} seed {seed} grid")
+        np.testing.assert_array_equal(agents, fx[key + "__agents"][seed], err_msg=f"{name} seed {seed} agents")
+        np.testing.assert_array_equal(meta, fx[key + "__meta"][seed], err_msg=f"{name} seed {seed} meta")
+        assert mission == str(fx[key + "__mission"][seed])
+        assert grid.shape == (spec["width"], spec["height"], 3)
+
+
+@pytest.mark.parametrize("group,name,agents,kw", [
+    ("cfg1_empty8", "MultiGrid-Empty-8x8-v0", 2, {}),
+    ("cfg2_redbluedoors8", "MultiGrid-RedBlueDoors-8x8-v0", 2, {}),
+    ("cfg3_blockedunlockpickup", "MultiGrid-BlockedUnlockPickup-v0", 2, {}),
+    ("cfg4_lockedhallway4", "MultiGrid-LockedHallway-4Rooms-v0", 4, {}),
+    ("cfg5_empty16", "MultiGrid-Empty-16x16-v0", 8, {}),
+    ("cfg5_empty16_nooverlap", "MultiGrid-Empty-16x16-v0", 8, {"allow_agent_overlap": False}),
+    ("short_lockedhallway2", "MultiGrid-LockedHallway-2Rooms-v0", 2, {"max_steps": 30}),
+])
+def test_registry_spec_matches_reference_env(group, name, agents, kw):
+    """make_spec() derives the same geometry and flags the reference classes report about themselves."""
+    from golden_util import load_group
+    ref_spec, _ = load_group(group)
+    spec, _ = envs.make_spec(name, num_agents=agents, **kw)
+    ref_spec.pop("mission")
+    spec.pop("mission")
+    assert spec == ref_spec
