@@ -11,7 +11,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libmgrid_hip.so")
+LIB_PATH = os.environ.get("MGRID_LIB", os.path.join(PKG_DIR, "libmgrid_hip.so"))
 SRC_PATH = os.path.join(PKG_DIR, "csrc", "mgrid.hip")
 INCLUDE_DIR = os.path.join(ROOT, "include")
 

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -52,11 +53,28 @@ constexpr uint32_t LAYOUT_STRIDE = 7919;  // layout of episode k of env g: (g + 
 
 constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 
+struct LdsMap {
+    int hdr;    // [ET][HS]      header blocks of the wave's environments
+    int fcv;    // [ET][A+2] u16 front-cell cache: packed cell in front of each agent (+ 2 door cells)
+    int fci;    // [ET][A+2] u16 cell index of each cache entry | FC_DIRTY, or FC_NONE
+    int act;    // [ET][A]   u8  actions
+    int ord;    // [ET][A]   u8  order in which agents act
+    int rewm;   // [ET][A]   u8  reward of agent k = rewm * R
+    int tout;   // [ET][A]   u8  terminated as returned to the caller
+    int oterm;  // [ET][A]   u8  terminated as seen by gen_obs
+    int flag;   // [ET][2]   u8  truncated, will-reset
+    int R;      // [ET]      f64 _reward() of this step
+    int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
+    int grid;   // [NE][GS]      grids of the sub-tile being observed
+    int img;    // [NE*A][3VV]+32 image bytes of the sub-tile, in output order
+};
+
 struct KParams {
     // configuration
     int kind, W, H, A, max_steps;
     int overlap, joint, succ_any, fail_any, num_rooms, autoreset;
-    int E, NE, HS, GS, num_layouts;
+    int E, NE, G, HS, GS, num_layouts;
+    uint32_t magic_a, magic_per;  // multiply-high constants for division by A and by GS / 16
     uint32_t env_offset;
     uint64_t seed;
     uint32_t serial;  // reset launches so far (0: the first reset starts the episode counters)
@@ -78,9 +96,13 @@ struct KParams {
     float *reward;
     uint8_t *terminated;
     uint8_t *truncated;
-    // LDS carve-up (byte offsets)
-    int o_hdr, o_grid, o_img, o_act, o_ord, o_tout, o_oterm, o_flag, o_dirty, o_rew;
+    LdsMap o;
+#ifdef MGRID_EXPERIMENT
+    int dbg;  // phase-ablation bits of the diagnostic build (tools/exp_phase.py); never in the product build
+#endif
 };
+
+constexpr uint32_t FC_DIRTY = 0x8000, FC_NONE = 0x7FFF;
 
 __device__ __forceinline__ uint32_t pack_cell(uint32_t t, uint32_t c, uint32_t s) {
     // "opaque" restates see_behind() == False, multigrid/utils/obs.py:44-61
@@ -100,47 +122,80 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// A workgroup here is exactly one wavefront.  LDS instructions of one wavefront execute in issue
+// order, so a lane sees what another lane wrote earlier in program order; all that is needed
+// between phases is to stop the compiler from moving LDS accesses across the phase boundary.
+// Unlike __syncthreads() this does not wait for outstanding global loads and stores.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// n / d for small n, with magic = floor(2^32 / d) + 1 (0 stands for d == 1)
+__device__ __forceinline__ int udiv(int n, uint32_t magic) {
+    return magic ? static_cast<int>(__umulhi(static_cast<uint32_t>(n), magic)) : n;
+}
+
+__device__ __forceinline__ int pick_layout(const KParams &p, int env, uint32_t episode) {
+    return static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
+                             static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
+                            static_cast<uint64_t>(p.num_layouts));
+}
+
 // ---- act: one lane per environment -------------------------------------------------------------
 
 struct EnvView {
-    uint8_t *h;        // header block in LDS
-    uint16_t *g;       // grid block in LDS
-    uint8_t *rows;     // agent rows
-    double *rew;       // [A]
-    uint8_t *tout;     // [A] terminated as returned to the caller
+    uint8_t *rows;   // agent rows in LDS
+    uint16_t *fcv;   // front-cell cache values
+    uint16_t *fci;   // front-cell cache indices
+    uint8_t *rewm;   // [A] reward multipliers
+    uint8_t *tout;   // [A] terminated as returned to the caller
     uint32_t flags;
-    double R;          // _reward(), multigrid/base.py:655-659
+    int A, NC;
 };
 
 // every agent counts, terminated ones included: multigrid/base.py:485,512
-__device__ __forceinline__ bool agent_at(const uint8_t *rows, int A, int x, int y) {
+__device__ __forceinline__ bool agent_at(const EnvView &ev, int x, int y) {
     bool hit = false;
-    for (int k = 0; k < A; ++k) hit |= (rows[8 * k + R_X] == x) & (rows[8 * k + R_Y] == y);
+    for (int k = 0; k < ev.A; ++k) {
+        const uint32_t xy = *reinterpret_cast<const uint16_t *>(ev.rows + 8 * k);
+        hit |= xy == static_cast<uint32_t>(x | (y << 8));
+    }
     return hit;
+}
+
+// A grid cell changes: every cache entry that aliases the cell takes the new value, and the
+// acting agent's entry is marked for write-back.
+__device__ __forceinline__ void set_cell(EnvView &ev, int entry, uint32_t ci, uint32_t value) {
+    for (int j = 0; j < ev.NC; ++j)
+        if ((ev.fci[j] & FC_NONE) == ci) ev.fcv[j] = static_cast<uint16_t>(value);
+    ev.fci[entry] = static_cast<uint16_t>(ci | FC_DIRTY);
 }
 
 // on_success, multigrid/base.py:535-562.  `hook` is false for the calls made from
 // handle_actions with an empty terminations dict (base.py:492), which change no termination
-// in mode "any".
+// in mode "any".  The reward _reward() is the same number R for every call within one step, so
+// "rewards[k] = R" is kept as a multiplier 1 and LockedHallway's "+= R" as multiplier + 1.
 __device__ __forceinline__ void on_success(const KParams &p, EnvView &ev, int i, bool hook) {
     if (p.succ_any) {
         if (hook)
-            for (int k = 0; k < p.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
+            for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
     } else {
         ev.rows[8 * i + R_TERM] = 1;
         if (hook) ev.tout[i] = 1;
     }
     if (p.joint)
-        for (int k = 0; k < p.A; ++k) ev.rew[k] = ev.R;
+        for (int k = 0; k < ev.A; ++k) ev.rewm[k] = 1;
     else
-        ev.rew[i] = ev.R;
+        ev.rewm[i] = 1;
 }
 
 // on_failure, multigrid/base.py:564-585
 __device__ __forceinline__ void on_failure(const KParams &p, EnvView &ev, int i, bool hook) {
     if (p.fail_any) {
         if (hook)
-            for (int k = 0; k < p.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
+            for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
     } else {
         ev.rows[8 * i + R_TERM] = 1;
         if (hook) ev.tout[i] = 1;
@@ -150,34 +205,42 @@ __device__ __forceinline__ void on_failure(const KParams &p, EnvView &ev, int i,
 // MultiGridEnv.step up to (not including) gen_obs, then the subclass hook:
 // multigrid/base.py:395-396,440-533 and redbluedoors.py:176-185,
 // blockedunlockpickup.py:165-167, locked_hallway.py:200-215.
+//
+// The grid itself is not in LDS here.  Each agent acts once per step and only its own action
+// moves or turns it, so the cell in front of every agent is known before the first action: those
+// A cells (plus the two RedBlueDoors doors) were gathered into the front-cell cache, which is all
+// of the grid this phase ever reads or writes.
 __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
-    const int A = p.A, W = p.W, H = p.H;
+    const int A = p.A, H = p.H;
+    uint8_t *h = lds + p.o.hdr + slot * p.HS;
     EnvView ev;
-    ev.h = lds + p.o_hdr + slot * p.HS;
-    ev.g = reinterpret_cast<uint16_t *>(lds + p.o_grid + slot * p.GS);
-    ev.rows = ev.h + H_ROWS;
-    ev.rew = reinterpret_cast<double *>(lds + p.o_rew) + slot * A;
-    ev.tout = lds + p.o_tout + slot * A;
-    uint8_t *oterm = lds + p.o_oterm + slot * A;
-    uint16_t *dirty = reinterpret_cast<uint16_t *>(lds + p.o_dirty) + slot * A;
-    const uint8_t *actb = lds + p.o_act + slot * A;
-    uint8_t *ordb = lds + p.o_ord + slot * A;
+    ev.A = A;
+    ev.NC = A + 2;
+    ev.rows = h + H_ROWS;
+    ev.fcv = reinterpret_cast<uint16_t *>(lds + p.o.fcv) + slot * ev.NC;
+    ev.fci = reinterpret_cast<uint16_t *>(lds + p.o.fci) + slot * ev.NC;
+    ev.rewm = lds + p.o.rewm + slot * A;
+    ev.tout = lds + p.o.tout + slot * A;
+    uint8_t *oterm = lds + p.o.oterm + slot * A;
+    const uint8_t *actb = lds + p.o.act + slot * A;
+    uint8_t *ordb = lds + p.o.ord + slot * A;
 
-    const int step = *reinterpret_cast<int *>(ev.h + H_STEP) + 1;  // base.py:395
-    *reinterpret_cast<int *>(ev.h + H_STEP) = step;
-    ev.flags = ev.h[H_FLAGS];
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
+    const int step = static_cast<int>(h0.x) + 1;  // base.py:395
+    *reinterpret_cast<int *>(h + H_STEP) = step;
+    ev.flags = h0.z & 0xFF;
     const uint32_t was_over = ev.flags & FLAG_OVER;
-    ev.R = 1.0 - 0.9 * (static_cast<double>(step) / static_cast<double>(p.max_steps));
-    const int red_x = ev.h[H_META], red_y = ev.h[H_META + 1];
-    const int blue_x = ev.h[H_META + 2], blue_y = ev.h[H_META + 3];
+    const int blue_x = (h0.w >> 16) & 0xFF, blue_y = h0.w >> 24;
     const bool rbd = p.kind == MG_KIND_REDBLUEDOORS;
+    reinterpret_cast<double *>(lds + p.o.R)[slot] =
+        1.0 - 0.9 * (static_cast<double>(step) / static_cast<double>(p.max_steps));  // base.py:655-659
 
     if (p.order == nullptr) {
         // uniform random permutation, keyed by (seed, global environment index, episode, step) so
         // that it does not depend on how launches are issued (eager, graph replay, sharding);
         // stands in for np_random.random(A).argsort() of base.py:457-461
         const uint64_t gid = static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env);
-        const uint64_t epi = *reinterpret_cast<const uint32_t *>(ev.h + H_EPISODE);
+        const uint64_t epi = h0.y;
         uint64_t st = mix64(mix64(p.seed ^ (gid << 20)) ^ (epi << 32) ^ static_cast<uint64_t>(step));
         for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
         for (int k = A - 1; k > 0; --k) {
@@ -189,28 +252,25 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
         }
     }
 
-    for (int k = 0; k < A; ++k) {
-        ev.rew[k] = 0.0;  // base.py:454
-        dirty[k] = 0xFFFF;
-    }
+    for (int k = 0; k < A; ++k) ev.rewm[k] = 0;  // base.py:454
 
     for (int n = 0; n < A; ++n) {  // base.py:464
         const int i = ordb[n];
         if (i >= A) continue;
         uint8_t *a = ev.rows + 8 * i;
-        if (a[R_TERM]) continue;  // base.py:467
+        const uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+        if ((r.x >> 24) & 0xFF) continue;  // base.py:467
         const int act = actb[i];
-        const int dir = a[R_DIR];
+        const int dir = (r.x >> 16) & 0xFF;
         if (act == ACT_LEFT) { a[R_DIR] = static_cast<uint8_t>((dir + 3) & 3); continue; }   // :471-472
         if (act == ACT_RIGHT) { a[R_DIR] = static_cast<uint8_t>((dir + 1) & 3); continue; }  // :475-476
         if (act >= ACT_DONE) continue;                                                        // :527-528
-        const int fx = a[R_X] + dir_dx(dir), fy = a[R_Y] + dir_dy(dir);  // agent.py:153-160
-        if (static_cast<unsigned>(fx) >= static_cast<unsigned>(W) ||
-            static_cast<unsigned>(fy) >= static_cast<unsigned>(H))
-            continue;  // cannot happen inside border walls; keeps the LDS access in range
-        const int ci = fx * H + fy;
-        const uint32_t w = ev.g[ci];
+        const uint32_t ci = ev.fci[i] & FC_NONE;
+        if (ci == FC_NONE) continue;  // front cell outside the grid: cannot happen inside border walls
+        const int fx = (r.x & 0xFF) + dir_dx(dir), fy = ((r.x >> 8) & 0xFF) + dir_dy(dir);  // agent.py:153-160
+        const uint32_t w = ev.fcv[i];
         const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
+        const int ct = r.y & 0xFF, cc = (r.y >> 8) & 0xFF, cs = (r.y >> 16) & 0xFF;
         const bool blue = rbd && fx == blue_x && fy == blue_y;
         // state of the world OBJECT: equals the cell except for the blue door re-closed by
         // redbluedoors.py:185 without a grid.update
@@ -219,42 +279,34 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
             const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
                                      (t == T_DOOR && so == S_OPEN);
             if (!can_overlap) continue;
-            if (!p.overlap && agent_at(ev.rows, A, fx, fy)) continue;
-            a[R_X] = static_cast<uint8_t>(fx);
-            a[R_Y] = static_cast<uint8_t>(fy);
+            if (!p.overlap && agent_at(ev, fx, fy)) continue;
+            *reinterpret_cast<uint16_t *>(a) = static_cast<uint16_t>(fx | (fy << 8));
             if (t == T_GOAL) on_success(p, ev, i, false);
             if (t == T_LAVA) on_failure(p, ev, i, false);
         } else if (act == ACT_PICKUP) {  // base.py:497-504
-            if ((t == T_KEY || t == T_BALL || t == T_BOX) && a[R_CT] == T_EMPTY) {
+            if ((t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY) {
                 a[R_CT] = static_cast<uint8_t>(t);
                 a[R_CC] = static_cast<uint8_t>(c);
                 a[R_CS] = static_cast<uint8_t>(s);
-                ev.g[ci] = CELL_EMPTY;
-                dirty[n] = static_cast<uint16_t>(ci);
+                set_cell(ev, i, ci, CELL_EMPTY);
             }
         } else if (act == ACT_DROP) {  // base.py:507-516
-            if (a[R_CT] != T_EMPTY && t == T_EMPTY && !agent_at(ev.rows, A, fx, fy)) {
-                ev.g[ci] = static_cast<uint16_t>(pack_cell(a[R_CT], a[R_CC], a[R_CS]));
+            if (ct != T_EMPTY && t == T_EMPTY && !agent_at(ev, fx, fy)) {
+                set_cell(ev, i, ci, pack_cell(ct, cc, cs));
                 a[R_CT] = T_EMPTY;
                 a[R_CC] = 0;
                 a[R_CS] = 0;
-                dirty[n] = static_cast<uint16_t>(ci);
             }
         } else {  // toggle, base.py:519-524
             if (t == T_DOOR) {  // Door.toggle, world_object.py:456-472
                 if (so == S_LOCKED) {
-                    if (a[R_CT] == T_KEY && a[R_CC] == c) {
-                        ev.g[ci] = static_cast<uint16_t>(pack_cell(T_DOOR, c, S_OPEN));
-                        dirty[n] = static_cast<uint16_t>(ci);
-                    }
+                    if (ct == T_KEY && cc == c) set_cell(ev, i, ci, pack_cell(T_DOOR, c, S_OPEN));
                 } else {
-                    ev.g[ci] = static_cast<uint16_t>(pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN));
-                    dirty[n] = static_cast<uint16_t>(ci);
+                    set_cell(ev, i, ci, pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN));
                     if (blue) ev.flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
                 }
             } else if (t == T_BOX) {  // Box.toggle with no contents, world_object.py:653-659
-                ev.g[ci] = CELL_EMPTY;
-                dirty[n] = static_cast<uint16_t>(ci);
+                set_cell(ev, i, ci, CELL_EMPTY);
             }
         }
     }
@@ -267,19 +319,19 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     }
     const bool trunc = step >= p.max_steps;
 
-    // subclass hooks run on the returned dicts, agents in index order
+    // subclass hooks run on the returned dicts, agents in index order.  An agent whose action was
+    // "toggle" has neither moved nor turned, so its cache entry still is the cell in front of it.
     if (rbd) {  // redbluedoors.py:176-185
         for (int i = 0; i < A; ++i) {
             if (actb[i] != ACT_TOGGLE) continue;
             const uint8_t *a = ev.rows + 8 * i;
             const int fx = a[R_X] + dir_dx(a[R_DIR]), fy = a[R_Y] + dir_dy(a[R_DIR]);
             if (fx != blue_x || fy != blue_y) continue;
-            const uint32_t w = ev.g[blue_x * H + blue_y];
+            const uint32_t w = ev.fcv[A + 1];
             if ((w & 15) != T_DOOR) continue;
             const int so = (ev.flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((w >> 4) & 15);
             if (so != S_OPEN) continue;
-            const uint32_t red = ev.g[red_x * H + red_y];
-            if (((red >> 4) & 15) == S_OPEN) {
+            if (((ev.fcv[A] >> 4) & 15) == S_OPEN) {
                 on_success(p, ev, i, true);
             } else {
                 on_failure(p, ev, i, true);
@@ -292,36 +344,32 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     } else if (p.kind == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
         for (int i = 0; i < A; ++i) {
             if (actb[i] != ACT_TOGGLE) continue;
-            const uint8_t *a = ev.rows + 8 * i;
-            const int fx = a[R_X] + dir_dx(a[R_DIR]), fy = a[R_Y] + dir_dy(a[R_DIR]);
-            if (static_cast<unsigned>(fx) >= static_cast<unsigned>(W) ||
-                static_cast<unsigned>(fy) >= static_cast<unsigned>(H))
-                continue;
-            const uint32_t w = ev.g[fx * H + fy];
+            if ((ev.fci[i] & FC_NONE) == FC_NONE) continue;
+            const uint32_t w = ev.fcv[i];
             if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
             const uint32_t bit = 1u << ((w >> 8) & 7);
             if (ev.flags & bit & FLAG_LH_MASK) continue;
             ev.flags |= bit & FLAG_LH_MASK;
             if (p.joint)
-                for (int k = 0; k < A; ++k) ev.rew[k] += ev.R;
+                for (int k = 0; k < A; ++k) ev.rewm[k]++;
             else
-                ev.rew[i] += ev.R;
+                ev.rewm[i]++;
         }
         if (__popc(ev.flags & FLAG_LH_MASK) == p.num_rooms)
             for (int k = 0; k < A; ++k) ev.tout[k] = 1;
     }
 
     bool all_term = true;
-    double paid = 0.0;
+    int paid = 0;
     for (int k = 0; k < A; ++k) {
         all_term &= ev.tout[k] != 0;
-        paid += ev.rew[k];
+        paid += ev.rewm[k];
     }
     const bool over = trunc || all_term;
     if (over) ev.flags |= FLAG_OVER;
-    ev.h[H_FLAGS] = static_cast<uint8_t>(ev.flags);
+    h[H_FLAGS] = static_cast<uint8_t>(ev.flags);
 
-    uint8_t *fl = lds + p.o_flag + 2 * slot;
+    uint8_t *fl = lds + p.o.flag + 2 * slot;
     const bool will_reset = over && p.autoreset != MG_AUTORESET_NONE;
     fl[0] = trunc ? 1 : 0;
     fl[1] = will_reset ? 1 : 0;
@@ -333,56 +381,63 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
         atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
     }
-    if (paid != 0.0)
+    if (paid != 0) {
+        const double R = reinterpret_cast<const double *>(lds + p.o.R)[slot];
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
-                  static_cast<unsigned long long>(static_cast<long long>(paid * 16777216.0)));
+                  static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
+    }
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset) {
         uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
-        for (int n = 0; n < A; ++n) {
-            const uint32_t ci = dirty[n];
-            if (ci != 0xFFFF) gg[ci] = ev.g[ci];
+        for (int j = 0; j < ev.NC; ++j) {
+            const uint32_t e = ev.fci[j];
+            if (e & FC_DIRTY) gg[e & FC_NONE] = ev.fcv[j];
         }
     }
 }
 
-// Draw every live agent into the LDS grid copy, index order, later agents on top
-// (multigrid/utils/obs.py:157-165; single-agent environments draw nothing, obs.py:166-167).
-__device__ __forceinline__ void overlay_env(const KParams &p, uint8_t *lds, int slot) {
-    if (p.A <= 1) return;
-    const uint8_t *rows = lds + p.o_hdr + slot * p.HS + H_ROWS;
-    const uint8_t *oterm = lds + p.o_oterm + slot * p.A;
-    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o_grid + slot * p.GS);
-    for (int k = 0; k < p.A; ++k) {
+// Bring the LDS copy of one environment's grid up to date with this step's changes, then draw
+// every live agent into it, index order, later agents on top (multigrid/utils/obs.py:157-165;
+// single-agent environments draw nothing, obs.py:166-167).
+__device__ __forceinline__ void patch_and_overlay(const KParams &p, uint8_t *lds, int slot, int sub) {
+    const int A = p.A, NC = A + 2;
+    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + sub * p.GS);
+    if (p.mode == MODE_STEP) {
+        const uint16_t *fcv = reinterpret_cast<const uint16_t *>(lds + p.o.fcv) + slot * NC;
+        const uint16_t *fci = reinterpret_cast<const uint16_t *>(lds + p.o.fci) + slot * NC;
+        for (int j = 0; j < NC; ++j) {
+            const uint32_t e = fci[j];
+            if (e & FC_DIRTY) g[e & FC_NONE] = fcv[j];
+        }
+    }
+    if (A <= 1) return;
+    const uint8_t *rows = lds + p.o.hdr + slot * p.HS + H_ROWS;
+    const uint8_t *oterm = lds + p.o.oterm + slot * A;
+    for (int k = 0; k < A; ++k) {
         if (oterm[k]) continue;
-        const uint8_t *a = rows + 8 * k;
-        const unsigned x = a[R_X], y = a[R_Y];
+        const uint2 r = *reinterpret_cast<const uint2 *>(rows + 8 * k);
+        const unsigned x = r.x & 0xFF, y = (r.x >> 8) & 0xFF;
         if (x < static_cast<unsigned>(p.W) && y < static_cast<unsigned>(p.H))
-            g[x * p.H + y] = static_cast<uint16_t>(T_AGENT | (a[R_DIR] << 4) | (a[R_COLOR] << 8));
+            g[x * p.H + y] = static_cast<uint16_t>(T_AGENT | (((r.x >> 16) & 0xFF) << 4) | ((r.y >> 24) << 8));
     }
 }
 
-// Replace one environment's LDS + HBM state by a start state from the pool
+// Replace one environment's header in LDS and its grid in HBM by a start state from the pool
 // (MultiGridEnv.reset, multigrid/base.py:310-362, with the layout precomputed on the host).
-// Executed by the whole wavefront for one slot at a time.
+// Executed by the whole wavefront for one environment at a time.
 __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int slot, int env, int layout,
                                            uint32_t episode, int lane) {
     const uint4 *sh = reinterpret_cast<const uint4 *>(p.pool_hdr + static_cast<size_t>(layout) * p.HS);
     const uint4 *sg = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(layout) * p.GS);
-    uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o_hdr + slot * p.HS);
-    uint4 *dg = reinterpret_cast<uint4 *>(lds + p.o_grid + slot * p.GS);
+    uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr + slot * p.HS);
     uint4 *gg = reinterpret_cast<uint4 *>(p.grid + static_cast<size_t>(env) * p.GS);
     for (int i = lane; i < p.HS / 16; i += 64) {
         uint4 v = sh[i];
         if (i == 0) v.y = episode;  // keep the environment's own episode counter
         dh[i] = v;
     }
-    for (int i = lane; i < p.GS / 16; i += 64) {
-        const uint4 v = sg[i];
-        dg[i] = v;
-        gg[i] = v;
-    }
+    for (int i = lane; i < p.GS / 16; i += 64) gg[i] = sg[i];
 }
 
 // ---- observe: one lane per agent ------------------------------------------------------------------
@@ -487,184 +542,265 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------
+//
+// One wavefront owns ET = G * NE consecutive environments.  Header blocks of all ET live in LDS for
+// the whole launch; grids are brought in NE environments ("sub-tile", NE * A <= 64 agent lanes)
+// at a time for the observation passes.
 
 template <int V, bool SEE>
 __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int IMG = 3 * V * V;  // bytes per agent image
     const int lane = threadIdx.x;
-    const int A = p.A;
-    const int tile = blockIdx.x;
-    const int e0 = tile * p.NE;
-    const int ne = min(p.NE, p.E - e0);
-    const int np = ne * A;
-    const int my_slot = lane / A;          // observe phase: environment slot of this lane's agent
-    const int my_agent = lane - my_slot * A;
+    const int A = p.A, NE = p.NE, NC = A + 2;
+    const int ET = p.G * NE;
+    const int e0 = blockIdx.x * ET;
+    const int net = min(ET, p.E - e0);
+    const int nag = net * A;
+    int *lsrc = reinterpret_cast<int *>(lds + p.o.src);
 
-    // which environments of the tile take part (reset / obs modes may skip some)
-    bool active = lane < ne;
+    // which environments take part (a masked reset skips some)
+    bool active = lane < net;
     if (p.mode == MODE_RESET && active && p.mask) active = p.mask[e0 + lane] != 0;
     const uint64_t active_mask = __ballot(active);
-    const bool all_active = active_mask == ((ne == 64) ? ~0ull : ((1ull << ne) - 1ull));
     if (active_mask == 0) return;
 
-    // ---- stage -------------------------------------------------------------------------------
+    // ---- header blocks (and, for a step, actions and order) -> LDS ------------------------------------
     if (p.mode != MODE_RESET) {
         const uint4 *sh = reinterpret_cast<const uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
-        const uint4 *sg = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0) * p.GS);
-        uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o_hdr);
-        uint4 *dg = reinterpret_cast<uint4 *>(lds + p.o_grid);
-        const int nh = ne * p.HS / 16, ng = ne * p.GS / 16;
-        for (int i0 = 0; i0 < ng; i0 += 64 * 8) {
-            uint4 buf[8];
+        uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr);
+        const int nh = net * p.HS / 16;
+        for (int i0 = 0; i0 < nh; i0 += 64 * 4) {
+            uint4 buf[4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int i = i0 + c * 64 + lane;
-                if (i < ng) buf[c] = sg[i];
-            }
+            for (int c = 0; c < 4; ++c) buf[c] = sh[min(i0 + c * 64 + lane, nh - 1)];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < 4; ++c) {
                 const int i = i0 + c * 64 + lane;
-                if (i < ng) dg[i] = buf[c];
+                if (i < nh) dh[i] = buf[c];
             }
-        }
-        for (int i = lane; i < nh; i += 64) dh[i] = sh[i];
-        if (p.mode == MODE_STEP && lane < np) {
-            lds[p.o_act + lane] = p.actions[static_cast<size_t>(e0) * A + lane];
-            if (p.order) lds[p.o_ord + lane] = p.order[static_cast<size_t>(e0) * A + lane];
         }
     }
-    __syncthreads();
+    if (lane < ET) lsrc[lane] = -1;
+    if (p.mode == MODE_STEP) {
+        for (int s = lane; s < nag; s += 64) {
+            lds[p.o.act + s] = p.actions[static_cast<size_t>(e0) * A + s];
+            if (p.order) lds[p.o.ord + s] = p.order[static_cast<size_t>(e0) * A + s];
+        }
+    }
+    wave_sync();
 
-    // ---- reset mode: pull start states from the pool --------------------------------------------
     if (p.mode == MODE_RESET) {
+        // pull start states from the pool: header -> LDS, grid -> HBM
+        uint32_t episode = 0;
+        int layout = 0;
+        if (active) {
+            const int env = e0 + lane;
+            const uint32_t old = *reinterpret_cast<const uint32_t *>(p.hdr + static_cast<size_t>(env) * p.HS + H_EPISODE);
+            episode = p.serial == 0 ? 0u : old + 1u;
+            layout = p.layout_idx ? p.layout_idx[env] : pick_layout(p, env, episode);
+            layout = min(max(layout, 0), p.num_layouts - 1);
+            lsrc[lane] = layout;
+        }
         uint64_t m = active_mask;
         while (m) {
             const int s = __builtin_ctzll(m);
             m &= m - 1;
-            const int env = e0 + s;
-            const uint32_t old_episode = *reinterpret_cast<const uint32_t *>(
-                p.hdr + static_cast<size_t>(env) * p.HS + H_EPISODE);
-            const uint32_t episode = p.serial == 0 ? 0u : old_episode + 1u;
-            int layout;
-            if (p.layout_idx)
-                layout = p.layout_idx[env];
-            else
-                layout = static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
-                                           static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
-                                          static_cast<uint64_t>(p.num_layouts));
-            layout = min(max(layout, 0), p.num_layouts - 1);
-            reload_env(p, lds, s, env, layout, episode, lane);
+            reload_env(p, lds, s, e0 + s, __shfl(layout, s), __shfl(episode, s), lane);
         }
-        __syncthreads();
-        if (lane < np) lds[p.o_oterm + lane] = lds[p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent + R_TERM];
-        __syncthreads();
-    } else if (p.mode == MODE_OBS) {
-        if (lane < np) lds[p.o_oterm + lane] = lds[p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent + R_TERM];
-        __syncthreads();
+        wave_sync();
+    }
+    if (p.mode != MODE_STEP) {
+        for (int s = lane; s < nag; s += 64) {
+            const int slot = udiv(s, p.magic_a);
+            lds[p.o.oterm + s] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_TERM];
+        }
+        wave_sync();
     }
 
-    // ---- act -----------------------------------------------------------------------------------
+    // ---- act ---------------------------------------------------------------------------------------
     if (p.mode == MODE_STEP) {
-        if (lane < ne) act_env(p, lds, lane, e0 + lane);
-        __syncthreads();
+        // gather the cell in front of every agent (one lane per agent, all loads in flight)
+        uint16_t *fcv = reinterpret_cast<uint16_t *>(lds + p.o.fcv);
+        uint16_t *fci = reinterpret_cast<uint16_t *>(lds + p.o.fci);
+        for (int s0 = 0; s0 < nag; s0 += 64 * 4) {
+            uint16_t val[4];
+            uint32_t idx[4];
+            int at[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int s = min(s0 + c * 64 + lane, nag - 1);
+                const int slot = udiv(s, p.magic_a);
+                const int k = s - slot * A;
+                const uint32_t r = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + slot * p.HS + H_ROWS + 8 * k);
+                const int dir = (r >> 16) & 3;
+                const int fx = static_cast<int>(r & 0xFF) + dir_dx(dir), fy = static_cast<int>((r >> 8) & 0xFF) + dir_dy(dir);
+                const bool in = static_cast<unsigned>(fx) < static_cast<unsigned>(p.W) &&
+                                static_cast<unsigned>(fy) < static_cast<unsigned>(p.H);
+                idx[c] = in ? static_cast<uint32_t>(fx * p.H + fy) : FC_NONE;
+                at[c] = slot * NC + k;
+                val[c] = reinterpret_cast<const uint16_t *>(p.grid + static_cast<size_t>(e0 + slot) * p.GS)[in ? idx[c] : 0];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (s0 + c * 64 + lane < nag) {
+                    fcv[at[c]] = val[c];
+                    fci[at[c]] = static_cast<uint16_t>(idx[c]);
+                }
+            }
+        }
+        if (lane < net) {  // the two RedBlueDoors doors (entries A and A + 1)
+            uint32_t ir = FC_NONE, ib = FC_NONE;
+            uint16_t vr = 0, vb = 0;
+            if (p.kind == MG_KIND_REDBLUEDOORS) {
+                const uint32_t meta = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + lane * p.HS + H_META);
+                const uint16_t *gg = reinterpret_cast<const uint16_t *>(p.grid + static_cast<size_t>(e0 + lane) * p.GS);
+                ir = min((meta & 0xFF) * p.H + ((meta >> 8) & 0xFF), static_cast<uint32_t>(p.W * p.H - 1));
+                ib = min(((meta >> 16) & 0xFF) * p.H + (meta >> 24), static_cast<uint32_t>(p.W * p.H - 1));
+                vr = gg[ir];
+                vb = gg[ib];
+            }
+            fcv[lane * NC + A] = vr;
+            fci[lane * NC + A] = static_cast<uint16_t>(ir);
+            fcv[lane * NC + A + 1] = vb;
+            fci[lane * NC + A + 1] = static_cast<uint16_t>(ib);
+        }
+        wave_sync();
+        if (lane < net) act_env(p, lds, lane, e0 + lane);
+        wave_sync();
         if (p.autoreset == MG_AUTORESET_SAME_STEP) {
-            uint64_t m = __ballot(lane < ne && lds[p.o_flag + 2 * lane + 1] != 0);
+            uint64_t m = __ballot(lane < net && lds[p.o.flag + 2 * lane + 1] != 0);
             if (m) {
                 while (m) {
                     const int s = __builtin_ctzll(m);
                     m &= m - 1;
                     const int env = e0 + s;
-                    const uint32_t episode =
-                        *reinterpret_cast<const uint32_t *>(lds + p.o_hdr + s * p.HS + H_EPISODE) + 1u;
-                    const int layout =
-                        static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
-                                          static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
-                                         static_cast<uint64_t>(p.num_layouts));
-                    __syncthreads();
+                    const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HS + H_EPISODE) + 1u;
+                    const int layout = pick_layout(p, env, episode);
+                    wave_sync();
                     reload_env(p, lds, s, env, layout, episode, lane);
-                    __syncthreads();
-                    if (lane < A) lds[p.o_oterm + s * A + lane] = lds[p.o_hdr + s * p.HS + H_ROWS + 8 * lane + R_TERM];
+                    if (lane == 0) lsrc[s] = layout;
+                    for (int j = lane; j < NC; j += 64) fci[s * NC + j] = FC_NONE;  // the fresh grid takes no patches
+                    wave_sync();
+                    if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HS + H_ROWS + 8 * lane + R_TERM];
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
     }
 
-    // ---- observe ----------------------------------------------------------------------------------
-    const bool want_img = p.image != nullptr;
-    const size_t out_base = (static_cast<size_t>(e0) * A) * IMG;  // byte offset of the tile's images
-    const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
-    if (want_img) {
-        if (lane < ne && ((active_mask >> lane) & 1)) overlay_env(p, lds, lane);
-        __syncthreads();
-        if (lane < np && ((active_mask >> my_slot) & 1)) {
-            const uint8_t *row = lds + p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent;
-            observe_agent<V, SEE>(p, row, lds + p.o_grid + my_slot * p.GS, lds + p.o_img + shift + lane * IMG);
-        }
-        __syncthreads();
-    }
-
-    // ---- write ----------------------------------------------------------------------------------
-    if (want_img) {
-        // The LDS stream sits `shift` bytes into its buffer so that LDS and HBM agree modulo 16.
-        uint8_t *gdst = p.image + out_base - shift;
-        const int total = shift + np * IMG;
-        const int nchunk = (total + 15) / 16;
-        for (int c = lane; c < nchunk; c += 64) {
-            const int b0 = 16 * c;
-            const bool whole = all_active && b0 >= shift && b0 + 16 <= total;
-            if (whole) {
-                *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o_img + b0);
-            } else {
-                for (int b = b0; b < b0 + 16; ++b) {
-                    if (b < shift || b >= total) continue;
-                    const int slot = ((b - shift) / IMG) / A;
-                    if ((active_mask >> slot) & 1) gdst[b] = lds[p.o_img + b];
-                }
-            }
-        }
-    }
-    if (lane < np && ((active_mask >> my_slot) & 1)) {
-        const size_t o = static_cast<size_t>(e0) * A + lane;
-        const uint8_t *row = lds + p.o_hdr + my_slot * p.HS + H_ROWS + 8 * my_agent;
-        if (p.direction) p.direction[o] = row[R_DIR];
+    // ---- per-agent scalars: one coalesced element per lane ---------------------------------------------
+    for (int s = lane; s < nag; s += 64) {
+        const int slot = udiv(s, p.magic_a);
+        if (!((active_mask >> slot) & 1)) continue;
+        const size_t o = static_cast<size_t>(e0) * A + s;
+        if (p.direction) p.direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
         if (p.mode == MODE_STEP) {
-            if (p.reward) p.reward[o] = static_cast<float>(reinterpret_cast<const double *>(lds + p.o_rew)[lane]);
-            if (p.terminated) p.terminated[o] = lds[p.o_tout + lane];
-            if (p.truncated) p.truncated[o] = lds[p.o_flag + 2 * my_slot];
+            if (p.reward)
+                p.reward[o] = static_cast<float>(lds[p.o.rewm + s] * reinterpret_cast<const double *>(lds + p.o.R)[slot]);
+            if (p.terminated) p.terminated[o] = lds[p.o.tout + s];
+            if (p.truncated) p.truncated[o] = lds[p.o.flag + 2 * slot];
         }
     }
 
-    if (p.mode == MODE_STEP) {
-        if (p.autoreset == MG_AUTORESET_NEXT_STEP) {
-            uint64_t m = __ballot(lane < ne && lds[p.o_flag + 2 * lane + 1] != 0);
-            if (m) {
-                __syncthreads();
-                while (m) {
-                    const int s = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int env = e0 + s;
-                    const uint32_t episode =
-                        *reinterpret_cast<const uint32_t *>(lds + p.o_hdr + s * p.HS + H_EPISODE) + 1u;
-                    const int layout =
-                        static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
-                                          static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
-                                         static_cast<uint64_t>(p.num_layouts));
-                    __syncthreads();
-                    reload_env(p, lds, s, env, layout, episode, lane);
+    // ---- observe: NE environments at a time -------------------------------------------------------------
+    if (p.image != nullptr) {
+        const int my_slot = udiv(lane, p.magic_a);  // environment (within the sub-tile) of this lane's agent
+        const int my_agent = lane - my_slot * A;
+        const int per = p.GS / 16;
+        for (int s0 = 0; s0 < net; s0 += NE) {
+            const int ns = min(NE, net - s0);
+            const int np = ns * A;
+            const uint64_t sub_mask = (active_mask >> s0) & ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
+            if (sub_mask == 0) continue;
+            const bool all_active = sub_mask == ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
+
+            // grids of the sub-tile -> LDS (from the pool for environments that were just reset)
+            const int n16 = ns * per;
+            uint4 *dg = reinterpret_cast<uint4 *>(lds + p.o.grid);
+#ifdef MGRID_EXPERIMENT
+            if (!(p.dbg & 4))
+#endif
+            for (int i0 = 0; i0 < n16; i0 += 64 * 8) {
+                uint4 buf[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int i = min(i0 + c * 64 + lane, n16 - 1);
+                    const int sub = udiv(i, p.magic_per);
+                    const int src = lsrc[s0 + sub];
+                    const uint8_t *base = src < 0 ? p.grid + static_cast<size_t>(e0 + s0 + sub) * p.GS
+                                                  : p.pool_grid + static_cast<size_t>(src) * p.GS;
+                    buf[c] = reinterpret_cast<const uint4 *>(base)[i - sub * per];
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int i = i0 + c * 64 + lane;
+                    if (i < n16) dg[i] = buf[c];
                 }
             }
+            wave_sync();
+#ifdef MGRID_EXPERIMENT
+            if (!(p.dbg & 8))
+#endif
+            if (lane < ns && ((sub_mask >> lane) & 1)) patch_and_overlay(p, lds, s0 + lane, lane);
+            wave_sync();
+
+            const size_t out_base = (static_cast<size_t>(e0 + s0) * A) * IMG;  // byte offset of the sub-tile's images
+            // The LDS stream sits `shift` bytes into its buffer so that LDS and HBM agree modulo 16.
+            const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
+#ifdef MGRID_EXPERIMENT
+            if (!(p.dbg & 1))
+#endif
+            if (lane < np && ((sub_mask >> my_slot) & 1)) {
+                const uint8_t *row = lds + p.o.hdr + (s0 + my_slot) * p.HS + H_ROWS + 8 * my_agent;
+                observe_agent<V, SEE>(p, row, lds + p.o.grid + my_slot * p.GS, lds + p.o.img + shift + lane * IMG);
+            }
+            wave_sync();
+
+            uint8_t *gdst = p.image + out_base - shift;
+            const int total = shift + np * IMG;
+            const int nchunk = (total + 15) / 16;
+#ifdef MGRID_EXPERIMENT
+            if (!(p.dbg & 2))
+#endif
+            for (int c = lane; c < nchunk; c += 64) {
+                const int b0 = 16 * c;
+                if (all_active && b0 >= shift && b0 + 16 <= total) {
+                    *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o.img + b0);
+                } else {
+                    for (int b = b0; b < b0 + 16; ++b) {
+                        if (b < shift || b >= total) continue;
+                        const int slot = ((b - shift) / IMG) / A;
+                        if ((sub_mask >> slot) & 1) gdst[b] = lds[p.o.img + b];
+                    }
+                }
+            }
+            wave_sync();
         }
-        __syncthreads();
+    }
+
+    if (p.mode == MODE_STEP && p.autoreset == MG_AUTORESET_NEXT_STEP) {
+        uint64_t m = __ballot(lane < net && lds[p.o.flag + 2 * lane + 1] != 0);
+        if (m) {
+            wave_sync();
+            while (m) {
+                const int s = __builtin_ctzll(m);
+                m &= m - 1;
+                const int env = e0 + s;
+                const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HS + H_EPISODE) + 1u;
+                wave_sync();
+                reload_env(p, lds, s, env, pick_layout(p, env, episode), episode, lane);
+            }
+            wave_sync();
+        }
     }
     if (p.mode != MODE_OBS) {
-        // header block back to HBM (reset mode: only the environments that were reset)
+        // header blocks back to HBM (reset mode: only the environments that were reset)
         uint4 *dh = reinterpret_cast<uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
-        const uint4 *sh = reinterpret_cast<const uint4 *>(lds + p.o_hdr);
-        const int per = p.HS / 16;
-        for (int i = lane; i < ne * per; i += 64)
-            if ((active_mask >> (i / per)) & 1) dh[i] = sh[i];
+        const uint4 *sh = reinterpret_cast<const uint4 *>(lds + p.o.hdr);
+        const int per_h = p.HS / 16;
+        for (int i = lane; i < net * per_h; i += 64)
+            if ((active_mask >> udiv(i, per_h == 1 ? 0u : (0xFFFFFFFFu / per_h + 1u))) & 1) dh[i] = sh[i];
     }
 }
 
@@ -843,33 +979,60 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     kp.env_offset = static_cast<uint32_t>(c.env_id_offset);
     kp.seed = c.seed;
 
-    // tile size: as many environments as give at most 64 agent lanes and fit a modest LDS budget
+    // Tile shape.  NE environments per observation pass give at most 64 agent lanes; one wavefront
+    // owns G such sub-tiles so that its act phase (one lane per environment) fills up to 64 lanes.
+    // Small batches get small tiles: the launch then has enough wavefronts to cover the chip and
+    // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
-    int ne = 64 / c.num_agents;
-    auto lds_for = [&](int n) {
-        const int np = n * c.num_agents;
+    auto lds_for = [&](int ne, int g) {
+        const int et = ne * g, nc = c.num_agents + 2, np = ne * c.num_agents;
         int o = 0;
         auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
-        kp.o_hdr = take(n * kp.HS);
-        kp.o_grid = take(n * kp.GS);
-        kp.o_img = take(np * img + 32);
-        kp.o_act = take(np);
-        kp.o_ord = take(np);
-        kp.o_tout = take(np);
-        kp.o_oterm = take(np);
-        kp.o_flag = take(2 * n);
-        kp.o_dirty = take(2 * np);
-        kp.o_rew = take(8 * np);
+        kp.o.hdr = take(et * kp.HS);
+        kp.o.fcv = take(2 * et * nc);
+        kp.o.fci = take(2 * et * nc);
+        kp.o.act = take(et * c.num_agents);
+        kp.o.ord = take(et * c.num_agents);
+        kp.o.rewm = take(et * c.num_agents);
+        kp.o.tout = take(et * c.num_agents);
+        kp.o.oterm = take(et * c.num_agents);
+        kp.o.flag = take(2 * et);
+        kp.o.R = take(8 * et);
+        kp.o.src = take(4 * et);
+        kp.o.grid = take(ne * kp.GS);
+        kp.o.img = take(np * img + 32);
         return o;
     };
-    while (ne > 1 && lds_for(ne) > 40 * 1024) --ne;
-    h->lds_bytes = static_cast<size_t>(lds_for(ne));
+    int ne = 64 / c.num_agents;
+    const int want_waves = 2048;
+    while (ne > 1 && (c.num_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
+    while (ne > 1 && lds_for(ne, 1) > 40 * 1024) --ne;
+    int g = 1;
+    while ((g + 1) * ne <= 64 && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
+           lds_for(ne, g + 1) <= 24 * 1024)
+        ++g;
+    if (const char *ev = getenv("MGRID_TILE")) {  // tuning override: "NE,G"
+        int a = 0, b = 0;
+        if (sscanf(ev, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && a * c.num_agents <= 64 && a * b <= 64) {
+            ne = a;
+            g = b;
+        }
+    }
+    h->lds_bytes = static_cast<size_t>(lds_for(ne, g));
+#ifdef MGRID_EXPERIMENT
+    if (const char *ev = getenv("MGRID_LDS_PAD")) h->lds_bytes += static_cast<size_t>(atoi(ev));
+    if (const char *ev = getenv("MGRID_DBG")) kp.dbg = atoi(ev);
+#endif
     if (h->lds_bytes > 64 * 1024) {
+        const size_t need = h->lds_bytes;
         delete h;
-        return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", h->lds_bytes);
+        return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", need);
     }
     kp.NE = ne;
-    h->num_tiles = (c.num_envs + ne - 1) / ne;
+    kp.G = g;
+    kp.magic_a = c.num_agents == 1 ? 0u : 0xFFFFFFFFu / c.num_agents + 1u;
+    kp.magic_per = kp.GS == 16 ? 0u : 0xFFFFFFFFu / (kp.GS / 16) + 1u;
+    h->num_tiles = (c.num_envs + ne * g - 1) / (ne * g);
 
     hipError_t e = hipSetDevice(c.device);
     if (e == hipSuccess) e = hipMalloc(&h->hdr, static_cast<size_t>(c.num_envs) * kp.HS);
