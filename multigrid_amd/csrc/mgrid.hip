@@ -15,9 +15,12 @@
 //
 // Device state (per handle)
 // -------------------------
-//   hdr   [E][HS] bytes, HS = 16 + 8 * roundup2(A):
-//           int32 step_count | uint32 episode | uint8 flags | 3 pad | uint8 meta[4] | agent rows
-//           agent row = x y dir terminated carry_type carry_color carry_state color
+//   hdr   [E][HS] bytes, HS = roundup16(16 + 8 * roundup2(A) + 2 * (A + 2)):
+//           int32 step_count | uint32 episode | uint8 flags | 3 pad | uint8 meta[4] | agent rows |
+//           front cells
+//           agent row   = x y dir terminated carry_type carry_color carry_state color
+//           front cells = uint16[A + 2]: the packed grid cell in front of each agent as of the end
+//                         of the last launch, then the RedBlueDoors red and blue door cells
 //   grid  [E][GS] bytes, GS = roundup16(2 * W * H): one uint16 per cell, index x * H + y,
 //           bits 0-3 type, 4-7 state, 8-14 color, 15 "opaque" (wall, or door that is not open).
 //   pool_hdr / pool_grid: the uploaded start states in the same two formats.
@@ -55,14 +58,13 @@ constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 
 struct LdsMap {
     int hdr;    // [ET][HS]      header blocks of the wave's environments
-    int fcv;    // [ET][A+2] u16 front-cell cache: packed cell in front of each agent (+ 2 door cells)
-    int fci;    // [ET][A+2] u16 cell index of each cache entry | FC_DIRTY, or FC_NONE
+    int log;    // [ET][A]   u32 cells written by this step, in order: cell index | packed cell << 16
     int act;    // [ET][A]   u8  actions
     int ord;    // [ET][A]   u8  order in which agents act
     int rewm;   // [ET][A]   u8  reward of agent k = rewm * R
     int tout;   // [ET][A]   u8  terminated as returned to the caller
     int oterm;  // [ET][A]   u8  terminated as seen by gen_obs
-    int flag;   // [ET][2]   u8  truncated, will-reset
+    int flag;   // [ET][4]   u8  truncated, will-reset, number of log entries, unused
     int R;      // [ET]      f64 _reward() of this step
     int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
     int grid;   // [NE][GS]      grids of the sub-tile being observed
@@ -70,15 +72,28 @@ struct LdsMap {
 };
 
 struct KParams {
-    // configuration
-    int kind, W, H, A, max_steps;
-    int overlap, joint, succ_any, fail_any, num_rooms, autoreset;
-    int E, NE, G, HS, GS, num_layouts;
-    uint32_t magic_a, magic_per;  // multiply-high constants for division by A and by GS / 16
+    // configuration, packed so that it occupies few scalar registers
+    uint32_t geo;   // W | H << 8 | A << 16 | NE << 24
+    uint32_t bits;  // kind (2) | overlap | joint | succ_any | fail_any | autoreset (2) | num_rooms (4) | G (8)
+    __host__ __device__ int W() const { return geo & 0xFF; }
+    __host__ __device__ int H() const { return (geo >> 8) & 0xFF; }
+    __host__ __device__ int A() const { return (geo >> 16) & 0xFF; }
+    __host__ __device__ int NE() const { return geo >> 24; }
+    __host__ __device__ int kind() const { return bits & 3; }
+    __host__ __device__ bool overlap() const { return (bits >> 2) & 1; }
+    __host__ __device__ bool joint() const { return (bits >> 3) & 1; }
+    __host__ __device__ bool succ_any() const { return (bits >> 4) & 1; }
+    __host__ __device__ bool fail_any() const { return (bits >> 5) & 1; }
+    __host__ __device__ int autoreset() const { return (bits >> 6) & 3; }
+    __host__ __device__ int num_rooms() const { return (bits >> 8) & 15; }
+    __host__ __device__ int G() const { return (bits >> 12) & 0xFF; }
+    int max_steps;
+    int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
+    uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
     uint32_t env_offset;
     uint64_t seed;
+    double reward_slope;  // 0.9 / max_steps
     uint32_t serial;  // reset launches so far (0: the first reset starts the episode counters)
-    int mode;
     // state
     uint8_t *hdr;
     uint8_t *grid;
@@ -99,10 +114,11 @@ struct KParams {
     LdsMap o;
 #ifdef MGRID_EXPERIMENT
     int dbg;  // phase-ablation bits of the diagnostic build (tools/exp_phase.py); never in the product build
+    unsigned long long *dbg_buf;  // [tiles][32] clock stamps of the diagnostic build
 #endif
 };
 
-constexpr uint32_t FC_DIRTY = 0x8000, FC_NONE = 0x7FFF;
+constexpr uint32_t FC_NONE = 0x7FFF;  // "no cell": the position lies outside the grid
 
 __device__ __forceinline__ uint32_t pack_cell(uint32_t t, uint32_t c, uint32_t s) {
     // "opaque" restates see_behind() == False, multigrid/utils/obs.py:44-61
@@ -112,9 +128,18 @@ __device__ __forceinline__ uint32_t pack_cell(uint32_t t, uint32_t c, uint32_t s
 constexpr uint32_t CELL_EMPTY = T_EMPTY;                        // (1, 0, 0)
 constexpr uint32_t CELL_WALL = T_WALL | (5u << 8) | (1u << 15);  // WALL_ENCODING (2, 5, 0), obs.py:13
 
-// DIR_TO_VEC, multigrid/core/constants.py:20-29
-__device__ __forceinline__ int dir_dx(int d) { return (d == 0) - (d == 2); }
-__device__ __forceinline__ int dir_dy(int d) { return (d == 1) - (d == 3); }
+// DIR_TO_VEC, multigrid/core/constants.py:20-29: right (1,0), down (0,1), left (-1,0), up (0,-1),
+// read out of two-bit fields holding component + 1
+__device__ __forceinline__ int dir_dx(int d) { return static_cast<int>((0x46u >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int d) { return static_cast<int>((0x19u >> (2 * d)) & 3u) - 1; }
+
+// Position one step ahead of an agent row word (x | y << 8 | dir << 16 | ...), packed x | y << 8;
+// a coordinate that leaves 0..255 wraps to a value no grid contains (agent.py:153-160).
+__device__ __forceinline__ uint32_t front_xy(uint32_t r) {
+    const uint32_t delta = static_cast<uint32_t>(0xFF0000FF01000001ull >> (16 * ((r >> 16) & 3)));
+    const uint32_t x = (r + delta) & 0xFF, y = ((r & 0xFF00) + (delta & 0xFF00)) & 0xFF00;
+    return x | y;
+}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -126,10 +151,13 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // order, so a lane sees what another lane wrote earlier in program order; all that is needed
 // between phases is to stop the compiler from moving LDS accesses across the phase boundary.
 // Unlike __syncthreads() this does not wait for outstanding global loads and stores.
+// The scheduling barrier also pins global loads that were issued early on purpose (the grid
+// prefetch) on their side of the phase boundary.
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // n / d for small n, with magic = floor(2^32 / d) + 1 (0 stands for d == 1)
@@ -143,62 +171,90 @@ __device__ __forceinline__ int pick_layout(const KParams &p, int env, uint32_t e
                             static_cast<uint64_t>(p.num_layouts));
 }
 
+// On-device agent order (used when the caller passes no order): a Fisher-Yates shuffle of
+// 0..A-1, for k = A-1 down to 1 swapping entries k and j = (field * (k + 1)) >> 16.  The 16-bit
+// fields are taken low half first from the 32-bit words fmix32(key + (q + 1) * 0x9E3779B9),
+// q = 0, 1, ...; the key mixes (seed, global environment index, episode, step) through the
+// murmur3 finalizer fmix32.  It stands in for np_random.random(A).argsort() of
+// multigrid/base.py:457-461 and does not depend on how launches are issued (eager, graph
+// replay, sharding).
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
+__device__ __forceinline__ uint32_t order_key(const KParams &p, int env, uint32_t episode, int step) {
+    uint32_t h = fmix32(static_cast<uint32_t>(p.seed) ^ (p.env_offset + static_cast<uint32_t>(env)));
+    h = fmix32(h ^ static_cast<uint32_t>(p.seed >> 32) ^ episode);
+    return fmix32(h ^ static_cast<uint32_t>(step));
+}
+__device__ __forceinline__ uint32_t order_field(uint32_t key, int f, uint32_t &word) {
+    if ((f & 1) == 0) word = fmix32(key + static_cast<uint32_t>((f >> 1) + 1) * 0x9E3779B9u);
+    return (word >> (16 * (f & 1))) & 0xFFFF;
+}
+
 // ---- act: one lane per environment -------------------------------------------------------------
 
+// index of the cell in front of an agent row (x y dir term), or FC_NONE outside the grid
+__device__ __forceinline__ uint32_t front_index(const KParams &p, uint32_t r) {
+    const uint32_t f = front_xy(r);
+    const uint32_t fx = f & 0xFF, fy = f >> 8;
+    return (fx < static_cast<uint32_t>(p.W()) && fy < static_cast<uint32_t>(p.H())) ? fx * p.H() + fy : FC_NONE;
+}
+
 struct EnvView {
-    uint8_t *rows;   // agent rows in LDS
-    uint16_t *fcv;   // front-cell cache values
-    uint16_t *fci;   // front-cell cache indices
-    uint8_t *rewm;   // [A] reward multipliers
-    uint8_t *tout;   // [A] terminated as returned to the caller
+    uint8_t *rows;        // agent rows in LDS
+    const uint16_t *fcv;  // front cells as of the start of the step (header block)
+    uint32_t *log;        // cells written during this step: index | value << 16, in order
+    int nlog;
+    uint8_t *rewm;        // [A] reward multipliers
+    uint8_t *tout;        // [A] terminated as returned to the caller
     uint32_t flags;
-    int A, NC;
+    int A;
 };
 
 // every agent counts, terminated ones included: multigrid/base.py:485,512
-__device__ __forceinline__ bool agent_at(const EnvView &ev, int x, int y) {
+__device__ __forceinline__ bool agent_at(const EnvView &ev, uint32_t xy) {
     bool hit = false;
-    for (int k = 0; k < ev.A; ++k) {
-        const uint32_t xy = *reinterpret_cast<const uint16_t *>(ev.rows + 8 * k);
-        hit |= xy == static_cast<uint32_t>(x | (y << 8));
-    }
+    for (int k = 0; k < ev.A; ++k) hit |= *reinterpret_cast<const uint16_t *>(ev.rows + 8 * k) == xy;
     return hit;
 }
 
-// A grid cell changes: every cache entry that aliases the cell takes the new value, and the
-// acting agent's entry is marked for write-back.
-__device__ __forceinline__ void set_cell(EnvView &ev, int entry, uint32_t ci, uint32_t value) {
-    for (int j = 0; j < ev.NC; ++j)
-        if ((ev.fci[j] & FC_NONE) == ci) ev.fcv[j] = static_cast<uint16_t>(value);
-    ev.fci[entry] = static_cast<uint16_t>(ci | FC_DIRTY);
+// current value of grid cell `ci`, given its value at the start of the step
+__device__ __forceinline__ uint32_t cell_now(const EnvView &ev, uint32_t ci, uint32_t at_start) {
+    uint32_t w = at_start;
+    for (int j = 0; j < ev.nlog; ++j) {
+        const uint32_t e = ev.log[j];
+        if ((e & 0xFFFF) == ci) w = e >> 16;
+    }
+    return w;
 }
 
-// on_success, multigrid/base.py:535-562.  `hook` is false for the calls made from
-// handle_actions with an empty terminations dict (base.py:492), which change no termination
-// in mode "any".  The reward _reward() is the same number R for every call within one step, so
-// "rewards[k] = R" is kept as a multiplier 1 and LockedHallway's "+= R" as multiplier + 1.
-__device__ __forceinline__ void on_success(const KParams &p, EnvView &ev, int i, bool hook) {
-    if (p.succ_any) {
-        if (hook)
-            for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
+// on_success, multigrid/base.py:535-562, as called from the environment hooks (a non-empty
+// terminations dict).  The reward _reward() is the same number R for every call within one step,
+// so "rewards[k] = R" is kept as a multiplier 1 and LockedHallway's "+= R" as multiplier + 1.
+__device__ __forceinline__ void hook_success(const KParams &p, EnvView &ev, int i) {
+    if (p.succ_any()) {
+        for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
     } else {
         ev.rows[8 * i + R_TERM] = 1;
-        if (hook) ev.tout[i] = 1;
+        ev.tout[i] = 1;
     }
-    if (p.joint)
+    if (p.joint())
         for (int k = 0; k < ev.A; ++k) ev.rewm[k] = 1;
     else
         ev.rewm[i] = 1;
 }
 
-// on_failure, multigrid/base.py:564-585
-__device__ __forceinline__ void on_failure(const KParams &p, EnvView &ev, int i, bool hook) {
-    if (p.fail_any) {
-        if (hook)
-            for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
+// on_failure, multigrid/base.py:564-585, as called from the environment hooks
+__device__ __forceinline__ void hook_failure(const KParams &p, EnvView &ev, int i) {
+    if (p.fail_any()) {
+        for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
     } else {
         ev.rows[8 * i + R_TERM] = 1;
-        if (hook) ev.tout[i] = 1;
+        ev.tout[i] = 1;
     }
 }
 
@@ -208,17 +264,18 @@ __device__ __forceinline__ void on_failure(const KParams &p, EnvView &ev, int i,
 //
 // The grid itself is not in LDS here.  Each agent acts once per step and only its own action
 // moves or turns it, so the cell in front of every agent is known before the first action: those
-// A cells (plus the two RedBlueDoors doors) were gathered into the front-cell cache, which is all
-// of the grid this phase ever reads or writes.
+// A cells (plus the two RedBlueDoors doors) travel with the header block - the observation pass of
+// the previous launch left them there.  Cells written during the step go to a short log that
+// later readers of the same cell consult.
 __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
-    const int A = p.A, H = p.H;
+    const int A = p.A();
     uint8_t *h = lds + p.o.hdr + slot * p.HS;
     EnvView ev;
     ev.A = A;
-    ev.NC = A + 2;
     ev.rows = h + H_ROWS;
-    ev.fcv = reinterpret_cast<uint16_t *>(lds + p.o.fcv) + slot * ev.NC;
-    ev.fci = reinterpret_cast<uint16_t *>(lds + p.o.fci) + slot * ev.NC;
+    ev.fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
+    ev.log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
+    ev.nlog = 0;
     ev.rewm = lds + p.o.rewm + slot * A;
     ev.tout = lds + p.o.tout + slot * A;
     uint8_t *oterm = lds + p.o.oterm + slot * A;
@@ -230,22 +287,17 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     *reinterpret_cast<int *>(h + H_STEP) = step;
     ev.flags = h0.z & 0xFF;
     const uint32_t was_over = ev.flags & FLAG_OVER;
-    const int blue_x = (h0.w >> 16) & 0xFF, blue_y = h0.w >> 24;
-    const bool rbd = p.kind == MG_KIND_REDBLUEDOORS;
+    const uint32_t blue_xy = h0.w >> 16;
+    const bool rbd = p.kind() == MG_KIND_REDBLUEDOORS;
     reinterpret_cast<double *>(lds + p.o.R)[slot] =
-        1.0 - 0.9 * (static_cast<double>(step) / static_cast<double>(p.max_steps));  // base.py:655-659
+        1.0 - static_cast<double>(step) * p.reward_slope;  // 1 - 0.9 * (step_count / max_steps), base.py:655-659
 
     if (p.order == nullptr) {
-        // uniform random permutation, keyed by (seed, global environment index, episode, step) so
-        // that it does not depend on how launches are issued (eager, graph replay, sharding);
-        // stands in for np_random.random(A).argsort() of base.py:457-461
-        const uint64_t gid = static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env);
-        const uint64_t epi = h0.y;
-        uint64_t st = mix64(mix64(p.seed ^ (gid << 20)) ^ (epi << 32) ^ static_cast<uint64_t>(step));
+        const uint32_t key = order_key(p, env, h0.y, step);
         for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
-        for (int k = A - 1; k > 0; --k) {
-            st = mix64(st + 0x9E3779B97F4A7C15ull);
-            const int j = static_cast<int>(((st >> 32) * static_cast<uint64_t>(k + 1)) >> 32);
+        uint32_t word = 0;
+        for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+            const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
             const uint8_t t = ordb[k];
             ordb[k] = ordb[j];
             ordb[j] = t;
@@ -258,57 +310,78 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
         const int i = ordb[n];
         if (i >= A) continue;
         uint8_t *a = ev.rows + 8 * i;
-        const uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+        uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+        const uint32_t w0 = ev.fcv[i];
         if ((r.x >> 24) & 0xFF) continue;  // base.py:467
         const int act = actb[i];
         const int dir = (r.x >> 16) & 0xFF;
-        if (act == ACT_LEFT) { a[R_DIR] = static_cast<uint8_t>((dir + 3) & 3); continue; }   // :471-472
-        if (act == ACT_RIGHT) { a[R_DIR] = static_cast<uint8_t>((dir + 1) & 3); continue; }  // :475-476
-        if (act >= ACT_DONE) continue;                                                        // :527-528
-        const uint32_t ci = ev.fci[i] & FC_NONE;
+        if (act == ACT_LEFT || act == ACT_RIGHT) {  // base.py:471-476
+            a[R_DIR] = static_cast<uint8_t>((dir + (act == ACT_LEFT ? 3 : 1)) & 3);
+            continue;
+        }
+        if (act >= ACT_DONE) continue;  // base.py:527-528
+        const uint32_t ci = front_index(p, r.x);
         if (ci == FC_NONE) continue;  // front cell outside the grid: cannot happen inside border walls
-        const int fx = (r.x & 0xFF) + dir_dx(dir), fy = ((r.x >> 8) & 0xFF) + dir_dy(dir);  // agent.py:153-160
-        const uint32_t w = ev.fcv[i];
+        const uint32_t fxy = front_xy(r.x);  // agent.py:153-160
+        const uint32_t w = cell_now(ev, ci, w0);
         const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
-        const int ct = r.y & 0xFF, cc = (r.y >> 8) & 0xFF, cs = (r.y >> 16) & 0xFF;
-        const bool blue = rbd && fx == blue_x && fy == blue_y;
+        const int ct = r.y & 0xFF, cc = (r.y >> 8) & 0xFF;
+        const bool blue = rbd && fxy == blue_xy;
         // state of the world OBJECT: equals the cell except for the blue door re-closed by
         // redbluedoors.py:185 without a grid.update
         const int so = (blue && (ev.flags & FLAG_STALE)) ? S_CLOSED : s;
+        bool write = false, moved = false;
+        uint32_t nv = 0;
         if (act == ACT_FORWARD) {  // base.py:479-494
             const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
                                      (t == T_DOOR && so == S_OPEN);
-            if (!can_overlap) continue;
-            if (!p.overlap && agent_at(ev, fx, fy)) continue;
-            *reinterpret_cast<uint16_t *>(a) = static_cast<uint16_t>(fx | (fy << 8));
-            if (t == T_GOAL) on_success(p, ev, i, false);
-            if (t == T_LAVA) on_failure(p, ev, i, false);
+            if (can_overlap && (p.overlap() || !agent_at(ev, fxy))) {
+                r.x = (r.x & 0xFFFF0000u) | fxy;
+                moved = true;
+                // on_success / on_failure with the empty terminations dict of base.py:492,494:
+                // mode "any" terminates nobody here, mode "all" terminates this agent
+                if (t == T_GOAL) {
+                    if (!p.succ_any()) r.x |= 1u << 24;
+                    if (p.joint())
+                        for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
+                    else
+                        ev.rewm[i] = 1;
+                }
+                if (t == T_LAVA && !p.fail_any()) r.x |= 1u << 24;
+            }
         } else if (act == ACT_PICKUP) {  // base.py:497-504
             if ((t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY) {
-                a[R_CT] = static_cast<uint8_t>(t);
-                a[R_CC] = static_cast<uint8_t>(c);
-                a[R_CS] = static_cast<uint8_t>(s);
-                set_cell(ev, i, ci, CELL_EMPTY);
+                r.y = (r.y & 0xFF000000u) | static_cast<uint32_t>(t | (c << 8) | (s << 16));
+                moved = true;
+                write = true;
+                nv = CELL_EMPTY;
             }
         } else if (act == ACT_DROP) {  // base.py:507-516
-            if (ct != T_EMPTY && t == T_EMPTY && !agent_at(ev, fx, fy)) {
-                set_cell(ev, i, ci, pack_cell(ct, cc, cs));
-                a[R_CT] = T_EMPTY;
-                a[R_CC] = 0;
-                a[R_CS] = 0;
+            if (ct != T_EMPTY && t == T_EMPTY && !agent_at(ev, fxy)) {
+                write = true;
+                nv = pack_cell(ct, cc, (r.y >> 16) & 0xFF);
+                r.y = (r.y & 0xFF000000u) | T_EMPTY;
+                moved = true;
             }
         } else {  // toggle, base.py:519-524
             if (t == T_DOOR) {  // Door.toggle, world_object.py:456-472
                 if (so == S_LOCKED) {
-                    if (ct == T_KEY && cc == c) set_cell(ev, i, ci, pack_cell(T_DOOR, c, S_OPEN));
+                    if (ct == T_KEY && cc == c) {
+                        write = true;
+                        nv = pack_cell(T_DOOR, c, S_OPEN);
+                    }
                 } else {
-                    set_cell(ev, i, ci, pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN));
+                    write = true;
+                    nv = pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN);
                     if (blue) ev.flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
                 }
             } else if (t == T_BOX) {  // Box.toggle with no contents, world_object.py:653-659
-                set_cell(ev, i, ci, CELL_EMPTY);
+                write = true;
+                nv = CELL_EMPTY;
             }
         }
+        if (moved) *reinterpret_cast<uint2 *>(a) = r;
+        if (write) ev.log[ev.nlog++] = ci | (nv << 16);
     }
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
@@ -320,42 +393,44 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     const bool trunc = step >= p.max_steps;
 
     // subclass hooks run on the returned dicts, agents in index order.  An agent whose action was
-    // "toggle" has neither moved nor turned, so its cache entry still is the cell in front of it.
+    // "toggle" has neither moved nor turned, so its header entry still names the cell in front of it.
     if (rbd) {  // redbluedoors.py:176-185
         for (int i = 0; i < A; ++i) {
-            if (actb[i] != ACT_TOGGLE) continue;
-            const uint8_t *a = ev.rows + 8 * i;
-            const int fx = a[R_X] + dir_dx(a[R_DIR]), fy = a[R_Y] + dir_dy(a[R_DIR]);
-            if (fx != blue_x || fy != blue_y) continue;
-            const uint32_t w = ev.fcv[A + 1];
-            if ((w & 15) != T_DOOR) continue;
-            const int so = (ev.flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((w >> 4) & 15);
+            const int act = actb[i];
+            if (act != ACT_TOGGLE) continue;
+            if (front_xy(*reinterpret_cast<const uint32_t *>(ev.rows + 8 * i)) != blue_xy) continue;
+            const uint32_t wb = cell_now(ev, (blue_xy & 0xFF) * p.H() + (blue_xy >> 8), ev.fcv[A + 1]);
+            if ((wb & 15) != T_DOOR) continue;
+            const int so = (ev.flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
             if (so != S_OPEN) continue;
-            if (((ev.fcv[A] >> 4) & 15) == S_OPEN) {
-                on_success(p, ev, i, true);
+            const uint32_t wr = cell_now(ev, ((h0.w >> 0) & 0xFF) * p.H() + ((h0.w >> 8) & 0xFF), ev.fcv[A]);
+            if (((wr >> 4) & 15) == S_OPEN) {
+                hook_success(p, ev, i);
             } else {
-                on_failure(p, ev, i, true);
+                hook_failure(p, ev, i);
                 ev.flags |= FLAG_STALE;
             }
         }
-    } else if (p.kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
+    } else if (p.kind() == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
         for (int i = 0; i < A; ++i)
-            if (ev.rows[8 * i + R_CT] == T_BOX) on_success(p, ev, i, true);
-    } else if (p.kind == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
+            if (ev.rows[8 * i + R_CT] == T_BOX) hook_success(p, ev, i);
+    } else if (p.kind() == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
         for (int i = 0; i < A; ++i) {
-            if (actb[i] != ACT_TOGGLE) continue;
-            if ((ev.fci[i] & FC_NONE) == FC_NONE) continue;
-            const uint32_t w = ev.fcv[i];
+            const int act = actb[i];
+            if (act != ACT_TOGGLE) continue;
+            const uint32_t ci = front_index(p, *reinterpret_cast<const uint32_t *>(ev.rows + 8 * i));
+            if (ci == FC_NONE) continue;
+            const uint32_t w = cell_now(ev, ci, ev.fcv[i]);
             if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
             const uint32_t bit = 1u << ((w >> 8) & 7);
             if (ev.flags & bit & FLAG_LH_MASK) continue;
             ev.flags |= bit & FLAG_LH_MASK;
-            if (p.joint)
+            if (p.joint())
                 for (int k = 0; k < A; ++k) ev.rewm[k]++;
             else
                 ev.rewm[i]++;
         }
-        if (__popc(ev.flags & FLAG_LH_MASK) == p.num_rooms)
+        if (__popc(ev.flags & FLAG_LH_MASK) == p.num_rooms())
             for (int k = 0; k < A; ++k) ev.tout[k] = 1;
     }
 
@@ -369,10 +444,11 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     if (over) ev.flags |= FLAG_OVER;
     h[H_FLAGS] = static_cast<uint8_t>(ev.flags);
 
-    uint8_t *fl = lds + p.o.flag + 2 * slot;
-    const bool will_reset = over && p.autoreset != MG_AUTORESET_NONE;
+    uint8_t *fl = lds + p.o.flag + 4 * slot;
+    const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
     fl[0] = trunc ? 1 : 0;
     fl[1] = will_reset ? 1 : 0;
+    fl[2] = static_cast<uint8_t>(ev.nlog);
 
     // episode statistics: touched only when something happened (rare)
     int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
@@ -390,36 +466,236 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset) {
         uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
-        for (int j = 0; j < ev.NC; ++j) {
-            const uint32_t e = ev.fci[j];
-            if (e & FC_DIRTY) gg[e & FC_NONE] = ev.fcv[j];
+        for (int j = 0; j < ev.nlog; ++j) {
+            const uint32_t e = ev.log[j];
+            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
         }
     }
 }
 
-// Bring the LDS copy of one environment's grid up to date with this step's changes, then draw
-// every live agent into it, index order, later agents on top (multigrid/utils/obs.py:157-165;
-// single-agent environments draw nothing, obs.py:166-167).
-__device__ __forceinline__ void patch_and_overlay(const KParams &p, uint8_t *lds, int slot, int sub) {
-    const int A = p.A, NC = A + 2;
-    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + sub * p.GS);
-    if (p.mode == MODE_STEP) {
-        const uint16_t *fcv = reinterpret_cast<const uint16_t *>(lds + p.o.fcv) + slot * NC;
-        const uint16_t *fci = reinterpret_cast<const uint16_t *>(lds + p.o.fci) + slot * NC;
-        for (int j = 0; j < NC; ++j) {
-            const uint32_t e = fci[j];
-            if (e & FC_DIRTY) g[e & FC_NONE] = fcv[j];
+// ---- act, up to 8 agents: the same step with per-agent bytes packed into 64-bit registers -------------
+
+__device__ __forceinline__ uint32_t byte_of(uint64_t w, int k) { return static_cast<uint32_t>(w >> (8 * k)) & 0xFF; }
+
+// A (<= 8) consecutive bytes, as one aligned load when A is a power of two
+__device__ __forceinline__ uint64_t load_bytes(const uint8_t *ptr, int A) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    if (A == 8 && (a & 7) == 0) return *reinterpret_cast<const uint64_t *>(ptr);
+    if (A == 4 && (a & 3) == 0) return *reinterpret_cast<const uint32_t *>(ptr);
+    if (A == 2 && (a & 1) == 0) return *reinterpret_cast<const uint16_t *>(ptr);
+    uint64_t w = 0;
+    for (int k = 0; k < A; ++k) w |= static_cast<uint64_t>(ptr[k]) << (8 * k);
+    return w;
+}
+
+__device__ __forceinline__ void store_bytes(uint8_t *ptr, uint64_t w, int A) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    if (A == 8 && (a & 7) == 0) { *reinterpret_cast<uint64_t *>(ptr) = w; return; }
+    if (A == 4 && (a & 3) == 0) { *reinterpret_cast<uint32_t *>(ptr) = static_cast<uint32_t>(w); return; }
+    if (A == 2 && (a & 1) == 0) { *reinterpret_cast<uint16_t *>(ptr) = static_cast<uint16_t>(w); return; }
+    for (int k = 0; k < A; ++k) ptr[k] = static_cast<uint8_t>(w >> (8 * k));
+}
+
+// Same contract as act_env; `actw` / `ordw` hold the A action and order bytes (ordw is ignored when
+// the order is drawn on the device).
+__device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env, uint64_t actw, uint64_t ordw) {
+    const int A = p.A(), W = p.W(), H = p.H();
+    uint8_t *h = lds + p.o.hdr + slot * p.HS;
+    uint8_t *rows = h + H_ROWS;
+    const uint16_t *fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
+    uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
+    int nlog = 0;
+    const uint64_t ones = 0x0101010101010101ull >> (8 * (8 - A));  // byte k = 1 for k < A
+
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
+    const int step = static_cast<int>(h0.x) + 1;  // base.py:395
+    *reinterpret_cast<int *>(h + H_STEP) = step;
+    uint32_t flags = h0.z & 0xFF;
+    const uint32_t was_over = flags & FLAG_OVER;
+    const uint32_t red_xy = h0.w & 0xFFFF, blue_xy = h0.w >> 16;
+    const bool rbd = p.kind() == MG_KIND_REDBLUEDOORS;
+    const double R = 1.0 - static_cast<double>(step) * p.reward_slope;  // 1 - 0.9 * (step_count / max_steps), base.py:655-659
+    reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
+
+    if (p.order == nullptr) {  // see order_key()
+        const uint32_t key = order_key(p, env, h0.y, step);
+        ordw = 0x0706050403020100ull;
+        uint32_t word = 0;
+        for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+            const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+            const uint64_t d = byte_of(ordw, k) ^ byte_of(ordw, j);
+            ordw ^= (d << (8 * k)) ^ (d << (8 * j));
         }
     }
-    if (A <= 1) return;
-    const uint8_t *rows = lds + p.o.hdr + slot * p.HS + H_ROWS;
-    const uint8_t *oterm = lds + p.o.oterm + slot * A;
-    for (int k = 0; k < A; ++k) {
-        if (oterm[k]) continue;
-        const uint2 r = *reinterpret_cast<const uint2 *>(rows + 8 * k);
-        const unsigned x = r.x & 0xFF, y = (r.x >> 8) & 0xFF;
-        if (x < static_cast<unsigned>(p.W) && y < static_cast<unsigned>(p.H))
-            g[x * p.H + y] = static_cast<uint16_t>(T_AGENT | (((r.x >> 16) & 0xFF) << 4) | ((r.y >> 24) << 8));
+
+    uint64_t termw = 0, rewmw = 0;  // byte k: agent k terminated / reward multiplier
+#pragma unroll
+    for (int k = 0; k < 8; ++k) termw |= static_cast<uint64_t>(rows[8 * min(k, A - 1) + R_TERM]) << (8 * k);
+    termw &= ones * 0xFF;
+
+    for (int n = 0; n < A; ++n) {  // base.py:464
+        const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
+        uint8_t *a = rows + 8 * i;
+        const uint2 r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+        const uint32_t w0 = fcv[i];
+        const int act = byte_of(actw, i);
+        const bool alive = (r0.x >> 24) == 0;  // base.py:467
+        const int dir = (r0.x >> 16) & 3;
+        uint2 r = r0;
+        // left / right, base.py:471-476
+        const int turn = act == ACT_LEFT ? 3 : (act == ACT_RIGHT ? 1 : 0);
+        r.x = (r.x & 0xFF00FFFFu) | (static_cast<uint32_t>((dir + turn) & 3) << 16);
+        // the cell in front, agent.py:153-160
+        const uint32_t fxy = front_xy(r0.x);
+        const uint32_t fx = fxy & 0xFF, fy = fxy >> 8;
+        const bool on_cell = alive && act >= ACT_FORWARD && act <= ACT_TOGGLE &&
+                             fx < static_cast<uint32_t>(W) && fy < static_cast<uint32_t>(H);
+        const uint32_t ci = fx * H + fy;
+        uint32_t w = w0;
+#pragma unroll 1
+        for (int j = 0; j < nlog; ++j) {  // cells already written during this step
+            const uint32_t e = log[j];
+            if ((e & 0xFFFF) == ci) w = e >> 16;
+        }
+        const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
+        const int ct = r0.y & 0xFF, cc = (r0.y >> 8) & 0xFF, cs = (r0.y >> 16) & 0xFF;
+        const bool blue = rbd && fxy == blue_xy;
+        // state of the world OBJECT: equals the cell except for the blue door re-closed by
+        // redbluedoors.py:185 without a grid.update
+        const int so = (blue && (flags & FLAG_STALE)) ? S_CLOSED : s;
+        const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA || (t == T_DOOR && so == S_OPEN);
+        const bool fwd = on_cell && act == ACT_FORWARD && can_overlap;            // base.py:479-483
+        const bool drop = on_cell && act == ACT_DROP && ct != T_EMPTY && t == T_EMPTY;  // base.py:507-511
+        bool occupied = false;  // base.py:485,512: every agent counts, terminated ones included
+        if ((fwd && !p.overlap()) || drop)
+#pragma unroll 1
+            for (int k = 0; k < A; ++k) occupied |= *reinterpret_cast<const uint16_t *>(rows + 8 * k) == fxy;
+        const bool mv = fwd && !occupied;
+        const bool dr = drop && !occupied;
+        const bool pk = on_cell && act == ACT_PICKUP && (t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY;  // :497-504
+        const bool door = on_cell && act == ACT_TOGGLE && t == T_DOOR;  // Door.toggle, world_object.py:456-472
+        const bool unlock = door && so == S_LOCKED && ct == T_KEY && cc == c;
+        const bool flip = door && so != S_LOCKED;
+        const bool box = on_cell && act == ACT_TOGGLE && t == T_BOX;  // Box.toggle, no contents, world_object.py:653-659
+        if (mv) r.x = (r.x & 0xFFFF0000u) | fxy;  // base.py:489
+        // on_success / on_failure with the empty terminations dict of base.py:492,494: mode "any"
+        // terminates nobody here, mode "all" terminates this agent
+        const bool goal = mv && t == T_GOAL, lava = mv && t == T_LAVA;
+        if ((goal && !p.succ_any()) || (lava && !p.fail_any())) {
+            r.x |= 1u << 24;
+            termw |= 1ull << (8 * i);
+        }
+        if (goal) rewmw = p.joint() ? ones : ((rewmw & ~(0xFFull << (8 * i))) | (1ull << (8 * i)));  // base.py:558-562
+        if (pk) r.y = (r0.y & 0xFF000000u) | static_cast<uint32_t>(t | (c << 8) | (s << 16));
+        if (dr) r.y = (r0.y & 0xFF000000u) | T_EMPTY;
+        if (flip && blue) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+        if (alive && (r.x != r0.x || r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = r;
+        if (pk || dr || unlock || flip || box) {
+            const uint32_t nv = (pk || box) ? CELL_EMPTY
+                                : dr        ? pack_cell(ct, cc, cs)
+                                            : pack_cell(T_DOOR, c, (unlock || so != S_OPEN) ? S_OPEN : S_CLOSED);
+            log[nlog++] = ci | (nv << 16);
+        }
+    }
+
+    // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
+    store_bytes(lds + p.o.oterm + slot * A, termw, A);
+    uint64_t toutw = termw;
+    const bool trunc = step >= p.max_steps;
+
+    // subclass hooks run on the returned dicts, agents in index order.  An agent whose action was
+    // "toggle" has neither moved nor turned, so its header entry still names the cell in front of it.
+    bool term_all = false;  // a hook terminated every agent
+    uint64_t term_some = 0; // a hook terminated these agents (mode "all")
+    if (rbd) {  // redbluedoors.py:176-185
+        for (int i = 0; i < A; ++i) {
+            if (byte_of(actw, i) != ACT_TOGGLE) continue;
+            if (front_xy(*reinterpret_cast<const uint32_t *>(rows + 8 * i)) != blue_xy) continue;
+            uint32_t wb = fcv[A + 1], wr = fcv[A];
+            const uint32_t cb = (blue_xy & 0xFF) * H + (blue_xy >> 8), cr = (red_xy & 0xFF) * H + (red_xy >> 8);
+            for (int j = 0; j < nlog; ++j) {
+                const uint32_t e = log[j];
+                if ((e & 0xFFFF) == cb) wb = e >> 16;
+                if ((e & 0xFFFF) == cr) wr = e >> 16;
+            }
+            if ((wb & 15) != T_DOOR) continue;
+            const int so = (flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
+            if (so != S_OPEN) continue;
+            if (((wr >> 4) & 15) == S_OPEN) {  // on_success, base.py:535-562
+                if (p.succ_any()) term_all = true; else term_some |= 1ull << (8 * i);
+                rewmw = p.joint() ? ones : ((rewmw & ~(0xFFull << (8 * i))) | (1ull << (8 * i)));
+            } else {  // on_failure, base.py:564-585
+                if (p.fail_any()) term_all = true; else term_some |= 1ull << (8 * i);
+                flags |= FLAG_STALE;
+            }
+        }
+    } else if (p.kind() == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
+        for (int i = 0; i < A; ++i) {
+            if (rows[8 * i + R_CT] != T_BOX) continue;
+            term_all = true;  // this environment always terminates "any" (blockedunlockpickup.py:128)
+            rewmw = p.joint() ? ones : ((rewmw & ~(0xFFull << (8 * i))) | (1ull << (8 * i)));
+        }
+        if (!p.succ_any() && term_all) {  // not reachable through the registry; keeps base.py:553-556 exact
+            term_all = false;
+            for (int i = 0; i < A; ++i)
+                if (rows[8 * i + R_CT] == T_BOX) term_some |= 1ull << (8 * i);
+        }
+    } else if (p.kind() == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
+        for (int i = 0; i < A; ++i) {
+            if (byte_of(actw, i) != ACT_TOGGLE) continue;
+            const uint32_t ci = front_index(p, *reinterpret_cast<const uint32_t *>(rows + 8 * i));
+            if (ci == FC_NONE) continue;
+            uint32_t w = fcv[i];
+            for (int j = 0; j < nlog; ++j) {
+                const uint32_t e = log[j];
+                if ((e & 0xFFFF) == ci) w = e >> 16;
+            }
+            if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
+            const uint32_t bit = 1u << ((w >> 8) & 7);
+            if (flags & bit & FLAG_LH_MASK) continue;
+            flags |= bit & FLAG_LH_MASK;
+            rewmw += p.joint() ? ones : (1ull << (8 * i));
+        }
+    }
+    if (term_all) term_some = ones;
+    if (term_some) {  // hooks set both the agents' own flags and the returned dict
+        toutw |= term_some;
+        for (int k = 0; k < A; ++k)
+            if (byte_of(term_some, k)) rows[8 * k + R_TERM] = 1;
+    }
+    if (p.kind() == MG_KIND_LOCKEDHALLWAY && __popc(flags & FLAG_LH_MASK) == p.num_rooms())
+        toutw = ones;  // locked_hallway.py:213-215: only the returned dict
+
+    store_bytes(lds + p.o.tout + slot * A, toutw, A);
+    store_bytes(lds + p.o.rewm + slot * A, rewmw, A);
+    const bool all_term = toutw == ones;
+    const int paid = static_cast<int>((rewmw * 0x0101010101010101ull) >> 56);
+    const bool over = trunc || all_term;
+    if (over) flags |= FLAG_OVER;
+    h[H_FLAGS] = static_cast<uint8_t>(flags);
+
+    const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
+    *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * slot) =
+        (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
+
+    // episode statistics: touched only when something happened (rare)
+    int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
+    if (over && !was_over) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+    }
+    if (paid != 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+                  static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
+
+    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
+    if (!will_reset) {
+        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+        for (int j = 0; j < nlog; ++j) {
+            const uint32_t e = log[j];
+            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+        }
     }
 }
 
@@ -449,7 +725,7 @@ template <int V, bool SEE>
 __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *row, const uint8_t *gbytes,
                                               uint8_t *out) {
     constexpr int HALF = V / 2;
-    const int W = p.W, H = p.H;
+    const int W = p.W(), H = p.H();
     const int x = row[R_X], y = row[R_Y], dir = row[R_DIR];
     // forward f and right r unit vectors; view cell (u, v) sits (u - HALF) to the right of and
     // (V - 1 - v) ahead of the agent, which is the rotation table of obs.py:174-190
@@ -541,32 +817,54 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
     }
 }
 
+#ifdef MGRID_EXPERIMENT
+// Diagnostic build only: drain memory, read the shader clock, keep it in a buffer of its own.
+#define MG_STAMP(k)                                                                        \
+    do {                                                                                   \
+        if (p.dbg_buf) {                                                                   \
+            __builtin_amdgcn_s_waitcnt(0);                                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+            if (threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + (k)] = t_; \
+        }                                                                                  \
+    } while (0)
+#else
+#define MG_STAMP(k) do { } while (0)
+#endif
+
 // ---- the kernel ----------------------------------------------------------------------------------------
 //
 // One wavefront owns ET = G * NE consecutive environments.  Header blocks of all ET live in LDS for
 // the whole launch; grids are brought in NE environments ("sub-tile", NE * A <= 64 agent lanes)
 // at a time for the observation passes.
 
-template <int V, bool SEE>
+template <int V, bool SEE, int MODE>
 __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int IMG = 3 * V * V;  // bytes per agent image
     const int lane = threadIdx.x;
-    const int A = p.A, NE = p.NE, NC = A + 2;
-    const int ET = p.G * NE;
+    const int A = p.A(), NE = p.NE(), NC = A + 2;
+    const int ET = p.G() * NE;
     const int e0 = blockIdx.x * ET;
     const int net = min(ET, p.E - e0);
     const int nag = net * A;
     int *lsrc = reinterpret_cast<int *>(lds + p.o.src);
 
+    MG_STAMP(0);
+    // up to 8 agents: each environment's action and order bytes ride in two registers of its act lane
+    const bool small = A <= 8;
+    uint64_t actw = 0, ordw = 0;
+    if (MODE == MODE_STEP && small && lane < net) {
+        actw = load_bytes(p.actions + static_cast<size_t>(e0 + lane) * A, A);
+        if (p.order) ordw = load_bytes(p.order + static_cast<size_t>(e0 + lane) * A, A);
+    }
     // which environments take part (a masked reset skips some)
     bool active = lane < net;
-    if (p.mode == MODE_RESET && active && p.mask) active = p.mask[e0 + lane] != 0;
+    if (MODE == MODE_RESET && active && p.mask) active = p.mask[e0 + lane] != 0;
     const uint64_t active_mask = __ballot(active);
     if (active_mask == 0) return;
 
     // ---- header blocks (and, for a step, actions and order) -> LDS ------------------------------------
-    if (p.mode != MODE_RESET) {
+    if (MODE != MODE_RESET) {
         const uint4 *sh = reinterpret_cast<const uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
         uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr);
         const int nh = net * p.HS / 16;
@@ -582,7 +880,43 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         }
     }
     if (lane < ET) lsrc[lane] = -1;
-    if (p.mode == MODE_STEP) {
+    wave_sync();
+    const int per = p.GS / 16;
+    const bool want_img = p.image != nullptr;
+    const bool passes = want_img || MODE == MODE_STEP;
+    // Grid blocks travel HBM -> registers -> LDS one sub-tile ahead: the loads for sub-tile g + 1
+    // are issued before sub-tile g is computed and land in LDS after its observation has read
+    // the previous grid, just before its image is stored; so neither the load latency nor the
+    // completion of the image stores sits on the critical path.
+    uint4 gb0, gb1, gb2, gb3, gb4, gb5, gb6, gb7;
+    auto grid_src = [&](int s0, int i) -> const uint4 * {
+        const int sub = udiv(i, p.magic_per);
+        const int src = lsrc[s0 + sub];
+        const uint8_t *base = src < 0 ? p.grid + static_cast<size_t>(e0 + s0 + sub) * p.GS
+                      : p.pool_grid + static_cast<size_t>(src) * p.GS;  // just reset: from the pool
+        return reinterpret_cast<const uint4 *>(base) + (i - sub * per);
+    };
+#define MG_ISSUE1(c, r) r = *grid_src(s0_, min((c) * 64 + lane, n16_ - 1));
+#define MG_COMMIT1(c, r) if ((c) * 64 + lane < n16_) dg_[(c) * 64 + lane] = r;
+#define MG_EACH(OP) OP(0, gb0) OP(1, gb1) OP(2, gb2) OP(3, gb3) OP(4, gb4) OP(5, gb5) OP(6, gb6) OP(7, gb7)
+    auto issue = [&](int s0_) {
+        const int n16_ = min(NE, net - s0_) * per;
+        MG_EACH(MG_ISSUE1)
+    };
+    auto commit = [&](int s0_) {
+        const int n16_ = min(NE, net - s0_) * per;
+        uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
+        MG_EACH(MG_COMMIT1)
+        for (int i = 512 + lane; i < n16_; i += 64) dg_[i] = *grid_src(s0_, i);  // grids beyond 8 KiB per sub-tile
+    };
+#undef MG_ISSUE1
+#undef MG_COMMIT1
+#undef MG_EACH
+    // The first sub-tile's loads go out before anything else so that they overlap the act phase;
+    // environments that turn out to be reset are fetched again from the pool below.
+    if (passes && MODE != MODE_RESET) issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == MODE_STEP && !small) {
         for (int s = lane; s < nag; s += 64) {
             lds[p.o.act + s] = p.actions[static_cast<size_t>(e0) * A + s];
             if (p.order) lds[p.o.ord + s] = p.order[static_cast<size_t>(e0) * A + s];
@@ -590,7 +924,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     }
     wave_sync();
 
-    if (p.mode == MODE_RESET) {
+    if (MODE == MODE_RESET) {
         // pull start states from the pool: header -> LDS, grid -> HBM
         uint32_t episode = 0;
         int layout = 0;
@@ -610,7 +944,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         }
         wave_sync();
     }
-    if (p.mode != MODE_STEP) {
+    if (MODE != MODE_STEP) {
         for (int s = lane; s < nag; s += 64) {
             const int slot = udiv(s, p.magic_a);
             lds[p.o.oterm + s] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_TERM];
@@ -618,58 +952,19 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         wave_sync();
     }
 
+    MG_STAMP(1);
     // ---- act ---------------------------------------------------------------------------------------
-    if (p.mode == MODE_STEP) {
-        // gather the cell in front of every agent (one lane per agent, all loads in flight)
-        uint16_t *fcv = reinterpret_cast<uint16_t *>(lds + p.o.fcv);
-        uint16_t *fci = reinterpret_cast<uint16_t *>(lds + p.o.fci);
-        for (int s0 = 0; s0 < nag; s0 += 64 * 4) {
-            uint16_t val[4];
-            uint32_t idx[4];
-            int at[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int s = min(s0 + c * 64 + lane, nag - 1);
-                const int slot = udiv(s, p.magic_a);
-                const int k = s - slot * A;
-                const uint32_t r = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + slot * p.HS + H_ROWS + 8 * k);
-                const int dir = (r >> 16) & 3;
-                const int fx = static_cast<int>(r & 0xFF) + dir_dx(dir), fy = static_cast<int>((r >> 8) & 0xFF) + dir_dy(dir);
-                const bool in = static_cast<unsigned>(fx) < static_cast<unsigned>(p.W) &&
-                                static_cast<unsigned>(fy) < static_cast<unsigned>(p.H);
-                idx[c] = in ? static_cast<uint32_t>(fx * p.H + fy) : FC_NONE;
-                at[c] = slot * NC + k;
-                val[c] = reinterpret_cast<const uint16_t *>(p.grid + static_cast<size_t>(e0 + slot) * p.GS)[in ? idx[c] : 0];
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (s0 + c * 64 + lane < nag) {
-                    fcv[at[c]] = val[c];
-                    fci[at[c]] = static_cast<uint16_t>(idx[c]);
-                }
-            }
-        }
-        if (lane < net) {  // the two RedBlueDoors doors (entries A and A + 1)
-            uint32_t ir = FC_NONE, ib = FC_NONE;
-            uint16_t vr = 0, vb = 0;
-            if (p.kind == MG_KIND_REDBLUEDOORS) {
-                const uint32_t meta = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + lane * p.HS + H_META);
-                const uint16_t *gg = reinterpret_cast<const uint16_t *>(p.grid + static_cast<size_t>(e0 + lane) * p.GS);
-                ir = min((meta & 0xFF) * p.H + ((meta >> 8) & 0xFF), static_cast<uint32_t>(p.W * p.H - 1));
-                ib = min(((meta >> 16) & 0xFF) * p.H + (meta >> 24), static_cast<uint32_t>(p.W * p.H - 1));
-                vr = gg[ir];
-                vb = gg[ib];
-            }
-            fcv[lane * NC + A] = vr;
-            fci[lane * NC + A] = static_cast<uint16_t>(ir);
-            fcv[lane * NC + A + 1] = vb;
-            fci[lane * NC + A + 1] = static_cast<uint16_t>(ib);
+    if (MODE == MODE_STEP) {
+        if (lane < net) {
+            if (small)
+                act_env_small(p, lds, lane, e0 + lane, actw, ordw);
+            else
+                act_env(p, lds, lane, e0 + lane);
         }
         wave_sync();
-        if (lane < net) act_env(p, lds, lane, e0 + lane);
-        wave_sync();
-        if (p.autoreset == MG_AUTORESET_SAME_STEP) {
-            uint64_t m = __ballot(lane < net && lds[p.o.flag + 2 * lane + 1] != 0);
+        MG_STAMP(2);
+        if (p.autoreset() == MG_AUTORESET_SAME_STEP) {
+            uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
             if (m) {
                 while (m) {
                     const int s = __builtin_ctzll(m);
@@ -680,7 +975,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                     wave_sync();
                     reload_env(p, lds, s, env, layout, episode, lane);
                     if (lane == 0) lsrc[s] = layout;
-                    for (int j = lane; j < NC; j += 64) fci[s * NC + j] = FC_NONE;  // the fresh grid takes no patches
+                    if (lane == 0) lds[p.o.flag + 4 * s + 2] = 0;  // the fresh grid takes no patches
                     wave_sync();
                     if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HS + H_ROWS + 8 * lane + R_TERM];
                 }
@@ -689,80 +984,110 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         }
     }
 
-    // ---- per-agent scalars: one coalesced element per lane ---------------------------------------------
-    for (int s = lane; s < nag; s += 64) {
-        const int slot = udiv(s, p.magic_a);
-        if (!((active_mask >> slot) & 1)) continue;
-        const size_t o = static_cast<size_t>(e0) * A + s;
-        if (p.direction) p.direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
-        if (p.mode == MODE_STEP) {
-            if (p.reward)
-                p.reward[o] = static_cast<float>(lds[p.o.rewm + s] * reinterpret_cast<const double *>(lds + p.o.R)[slot]);
-            if (p.terminated) p.terminated[o] = lds[p.o.tout + s];
-            if (p.truncated) p.truncated[o] = lds[p.o.flag + 2 * slot];
-        }
-    }
-
+    MG_STAMP(3);
     // ---- observe: NE environments at a time -------------------------------------------------------------
-    if (p.image != nullptr) {
+    if (passes) {
         const int my_slot = udiv(lane, p.magic_a);  // environment (within the sub-tile) of this lane's agent
         const int my_agent = lane - my_slot * A;
-        const int per = p.GS / 16;
+        {
+            // re-fetch the first sub-tile if the reset path changed where any of its grids come from
+            bool moved = false;
+            for (int k = 0; k < min(NE, net); ++k) moved |= lsrc[k] >= 0;
+            if (moved || MODE == MODE_RESET) issue(0);
+            commit(0);
+        }
+        wave_sync();
         for (int s0 = 0; s0 < net; s0 += NE) {
             const int ns = min(NE, net - s0);
             const int np = ns * A;
             const uint64_t sub_mask = (active_mask >> s0) & ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
-            if (sub_mask == 0) continue;
             const bool all_active = sub_mask == ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
-
-            // grids of the sub-tile -> LDS (from the pool for environments that were just reset)
-            const int n16 = ns * per;
-            uint4 *dg = reinterpret_cast<uint4 *>(lds + p.o.grid);
+            const bool has_next = s0 + NE < net;
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 4))
 #endif
-            for (int i0 = 0; i0 < n16; i0 += 64 * 8) {
-                uint4 buf[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int i = min(i0 + c * 64 + lane, n16 - 1);
-                    const int sub = udiv(i, p.magic_per);
-                    const int src = lsrc[s0 + sub];
-                    const uint8_t *base = src < 0 ? p.grid + static_cast<size_t>(e0 + s0 + sub) * p.GS
-                                                  : p.pool_grid + static_cast<size_t>(src) * p.GS;
-                    buf[c] = reinterpret_cast<const uint4 *>(base)[i - sub * per];
+            if (has_next) issue(s0 + NE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 == 0) MG_STAMP(4);
+            const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
+            const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
+            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + my_slot * p.GS);
+            if (MODE == MODE_STEP) {
+                // cells changed by this step, replayed in order (one lane per environment)
+                if (lane < ns && ((sub_mask >> lane) & 1)) {
+                    const uint32_t *log = reinterpret_cast<const uint32_t *>(lds + p.o.log) + (s0 + lane) * A;
+                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + lane * p.GS);
+                    const int n = lds[p.o.flag + 4 * (s0 + lane) + 2];
+                    for (int j = 0; j < n; ++j) {
+                        const uint32_t e = log[j];
+                        g[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+                    }
                 }
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int i = i0 + c * 64 + lane;
-                    if (i < n16) dg[i] = buf[c];
-                }
+                wave_sync();
             }
-            wave_sync();
+            // front cells for the NEXT launch, taken before agents are drawn into the grid
+            if (MODE != MODE_OBS) {
+                if (mine) {
+                    const uint32_t ci = front_index(p, *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * my_agent));
+                    reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HS + p.HFC)[my_agent] =
+                        ci == FC_NONE ? static_cast<uint16_t>(0) : my_grid[ci];
+                }
+                if (p.kind() == MG_KIND_REDBLUEDOORS && lane < ns && ((sub_mask >> lane) & 1)) {
+                    uint8_t *h = lds + p.o.hdr + (s0 + lane) * p.HS;
+                    const uint32_t meta = *reinterpret_cast<const uint32_t *>(h + H_META);
+                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + lane * p.GS);
+                    const uint32_t last = static_cast<uint32_t>(p.W() * p.H() - 1);
+                    reinterpret_cast<uint16_t *>(h + p.HFC)[A] = g[min((meta & 0xFF) * p.H() + ((meta >> 8) & 0xFF), last)];
+                    reinterpret_cast<uint16_t *>(h + p.HFC)[A + 1] = g[min(((meta >> 16) & 0xFF) * p.H() + (meta >> 24), last)];
+                }
+                wave_sync();
+            }
+            if (s0 == 0) MG_STAMP(5);
+            // Draw every live agent into the grid copy; where several share a cell the highest index
+            // shows (multigrid/utils/obs.py:157-165: index order, later agents overwrite; single-agent
+            // environments draw nothing, obs.py:166-167).
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 8))
 #endif
-            if (lane < ns && ((sub_mask >> lane) & 1)) patch_and_overlay(p, lds, s0 + lane, lane);
+            if (want_img && A > 1 && mine && !lds[p.o.oterm + (s0 + my_slot) * A + my_agent]) {
+                const uint2 r = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
+                const uint32_t xy = r.x & 0xFFFF;
+                bool top = true;
+                for (int k = my_agent + 1; k < A; ++k) {
+                    const uint32_t rk = *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * k);
+                    top &= ((rk & 0xFFFF) != xy) | (lds[p.o.oterm + (s0 + my_slot) * A + k] != 0);
+                }
+                const unsigned x = xy & 0xFF, y = xy >> 8;
+                if (top && x < static_cast<unsigned>(p.W()) && y < static_cast<unsigned>(p.H()))
+                    my_grid[x * p.H() + y] = static_cast<uint16_t>(T_AGENT | (((r.x >> 16) & 0xFF) << 4) | ((r.y >> 24) << 8));
+            }
             wave_sync();
 
+            if (s0 == 0) MG_STAMP(6);
             const size_t out_base = (static_cast<size_t>(e0 + s0) * A) * IMG;  // byte offset of the sub-tile's images
             // The LDS stream sits `shift` bytes into its buffer so that LDS and HBM agree modulo 16.
             const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 1))
 #endif
-            if (lane < np && ((sub_mask >> my_slot) & 1)) {
-                const uint8_t *row = lds + p.o.hdr + (s0 + my_slot) * p.HS + H_ROWS + 8 * my_agent;
-                observe_agent<V, SEE>(p, row, lds + p.o.grid + my_slot * p.GS, lds + p.o.img + shift + lane * IMG);
-            }
+            if (want_img && mine)
+                observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * p.GS,
+                                      lds + p.o.img + shift + lane * IMG);
             wave_sync();
+            // the next sub-tile's grids may now replace this one's
+#ifdef MGRID_EXPERIMENT
+            if (!(p.dbg & 4))
+#endif
+            if (has_next) commit(s0 + NE);
 
+            if (s0 == 0) MG_STAMP(7);
             uint8_t *gdst = p.image + out_base - shift;
             const int total = shift + np * IMG;
             const int nchunk = (total + 15) / 16;
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 2))
 #endif
+            if (want_img)
             for (int c = lane; c < nchunk; c += 64) {
                 const int b0 = 16 * c;
                 if (all_active && b0 >= shift && b0 + 16 <= total) {
@@ -776,11 +1101,27 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 }
             }
             wave_sync();
+            if (s0 == 0) MG_STAMP(8);
         }
     }
 
-    if (p.mode == MODE_STEP && p.autoreset == MG_AUTORESET_NEXT_STEP) {
-        uint64_t m = __ballot(lane < net && lds[p.o.flag + 2 * lane + 1] != 0);
+    // ---- per-agent scalars: one coalesced element per lane ---------------------------------------------
+    for (int s = lane; s < nag; s += 64) {
+        const int slot = udiv(s, p.magic_a);
+        if (!((active_mask >> slot) & 1)) continue;
+        const size_t o = static_cast<size_t>(e0) * A + s;
+        if (p.direction) p.direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
+        if (MODE == MODE_STEP) {
+            if (p.reward)
+                p.reward[o] = static_cast<float>(lds[p.o.rewm + s] * reinterpret_cast<const double *>(lds + p.o.R)[slot]);
+            if (p.terminated) p.terminated[o] = lds[p.o.tout + s];
+            if (p.truncated) p.truncated[o] = lds[p.o.flag + 4 * slot];
+        }
+    }
+
+    MG_STAMP(9);
+    if (MODE == MODE_STEP && p.autoreset() == MG_AUTORESET_NEXT_STEP) {
+        uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
         if (m) {
             wave_sync();
             while (m) {
@@ -794,7 +1135,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             wave_sync();
         }
     }
-    if (p.mode != MODE_OBS) {
+    if (MODE != MODE_OBS) {
         // header blocks back to HBM (reset mode: only the environments that were reset)
         uint4 *dh = reinterpret_cast<uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
         const uint4 *sh = reinterpret_cast<const uint4 *>(lds + p.o.hdr);
@@ -802,13 +1143,14 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         for (int i = lane; i < net * per_h; i += 64)
             if ((active_mask >> udiv(i, per_h == 1 ? 0u : (0xFFFFFFFFu / per_h + 1u))) & 1) dh[i] = sh[i];
     }
+    MG_STAMP(10);
 }
 
 // ---- reference-layout <-> device-layout conversion (debug / parity path) -------------------------------
 
 __global__ void mg_set_state_kernel(KParams p, const uint8_t *grid, const uint8_t *agents, const uint8_t *meta,
                                     const int32_t *steps, const uint8_t *flags) {
-    const int cells = p.W * p.H;
+    const int cells = p.W() * p.H();
     const size_t n = static_cast<size_t>(p.E) * cells;
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x) {
@@ -825,14 +1167,32 @@ __global__ void mg_set_state_kernel(KParams p, const uint8_t *grid, const uint8_
             if (meta)
                 for (int k = 0; k < 4; ++k) h[H_META + k] = meta[e * 4 + k];
             if (agents)
-                for (int k = 0; k < p.A * 8; ++k) h[H_ROWS + k] = agents[e * p.A * 8 + k];
+                for (int k = 0; k < p.A() * 8; ++k) h[H_ROWS + k] = agents[e * p.A() * 8 + k];
         }
+    }
+}
+
+// Recompute the front cells kept in the header blocks from the grid (after mg_set_state).
+__global__ void mg_refresh_front_kernel(KParams p) {
+    const int n = p.E * (p.A() + 2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int e = i / (p.A() + 2), k = i - e * (p.A() + 2);
+        uint8_t *h = p.hdr + static_cast<size_t>(e) * p.HS;
+        const uint16_t *g = reinterpret_cast<const uint16_t *>(p.grid + static_cast<size_t>(e) * p.GS);
+        uint32_t ci = FC_NONE;
+        if (k < p.A()) {
+            ci = front_index(p, *reinterpret_cast<const uint32_t *>(h + H_ROWS + 8 * k));
+        } else if (p.kind() == MG_KIND_REDBLUEDOORS) {
+            const int mx = h[H_META + 2 * (k - p.A())], my = h[H_META + 2 * (k - p.A()) + 1];
+            ci = min(static_cast<uint32_t>(mx * p.H() + my), static_cast<uint32_t>(p.W() * p.H() - 1));
+        }
+        reinterpret_cast<uint16_t *>(h + p.HFC)[k] = ci == FC_NONE ? static_cast<uint16_t>(0) : g[ci];
     }
 }
 
 __global__ void mg_get_state_kernel(KParams p, uint8_t *grid, uint8_t *agents, uint8_t *meta, int32_t *steps,
                                     uint8_t *flags) {
-    const int cells = p.W * p.H;
+    const int cells = p.W() * p.H();
     const size_t n = static_cast<size_t>(p.E) * cells;
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x) {
@@ -852,7 +1212,7 @@ __global__ void mg_get_state_kernel(KParams p, uint8_t *grid, uint8_t *agents, u
             if (meta)
                 for (int k = 0; k < 4; ++k) meta[e * 4 + k] = h[H_META + k];
             if (agents)
-                for (int k = 0; k < p.A * 8; ++k) agents[e * p.A * 8 + k] = h[H_ROWS + k];
+                for (int k = 0; k < p.A() * 8; ++k) agents[e * p.A() * 8 + k] = h[H_ROWS + k];
         }
     }
 }
@@ -910,20 +1270,21 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int V>
-void launch_v(const MgEnv *h, const KParams &kp, hipStream_t s) {
+template <int V, int MODE>
+void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
     if (h->cfg.see_through_walls)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE>), grid, block, h->lds_bytes, s, kp);
     else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE>), grid, block, h->lds_bytes, s, kp);
 }
 
+template <int MODE>
 int launch_tile(MgEnv *h, const KParams &kp, hipStream_t s) {
     switch (h->cfg.view_size) {
-        case 3: launch_v<3>(h, kp, s); break;
-        case 5: launch_v<5>(h, kp, s); break;
-        case 7: launch_v<7>(h, kp, s); break;
+        case 3: launch_vm<3, MODE>(h, kp, s); break;
+        case 5: launch_vm<5, MODE>(h, kp, s); break;
+        case 7: launch_vm<7, MODE>(h, kp, s); break;
         default: return fail(h, MG_EINVAL, "view_size %d not supported", h->cfg.view_size);
     }
     MG_HIP(h, hipGetLastError());
@@ -969,15 +1330,19 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     if (!h) return fail(nullptr, MG_EINVAL, "out of host memory");
     h->cfg = c;
     KParams &kp = h->kp;
-    kp.kind = c.kind; kp.W = c.width; kp.H = c.height; kp.A = c.num_agents; kp.max_steps = c.max_steps;
-    kp.overlap = c.allow_agent_overlap != 0; kp.joint = c.joint_reward != 0;
-    kp.succ_any = c.success_any != 0; kp.fail_any = c.failure_any != 0;
-    kp.num_rooms = c.num_rooms; kp.autoreset = c.autoreset;
+    kp.geo = static_cast<uint32_t>(c.width) | (static_cast<uint32_t>(c.height) << 8) |
+             (static_cast<uint32_t>(c.num_agents) << 16);
+    kp.bits = static_cast<uint32_t>(c.kind) | (c.allow_agent_overlap ? 4u : 0u) | (c.joint_reward ? 8u : 0u) |
+              (c.success_any ? 16u : 0u) | (c.failure_any ? 32u : 0u) | (static_cast<uint32_t>(c.autoreset) << 6) |
+              (static_cast<uint32_t>(c.num_rooms & 15) << 8);
+    kp.max_steps = c.max_steps;
     kp.E = c.num_envs;
-    kp.HS = 16 + 8 * round_up(c.num_agents, 2);
+    kp.HFC = 16 + 8 * round_up(c.num_agents, 2);
+    kp.HS = round_up(kp.HFC + 2 * (c.num_agents + 2), 16);
     kp.GS = round_up(2 * c.width * c.height, 16);
     kp.env_offset = static_cast<uint32_t>(c.env_id_offset);
     kp.seed = c.seed;
+    kp.reward_slope = 0.9 / static_cast<double>(c.max_steps);
 
     // Tile shape.  NE environments per observation pass give at most 64 agent lanes; one wavefront
     // owns G such sub-tiles so that its act phase (one lane per environment) fills up to 64 lanes.
@@ -985,30 +1350,31 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
     auto lds_for = [&](int ne, int g) {
-        const int et = ne * g, nc = c.num_agents + 2, np = ne * c.num_agents;
+        const int et = ne * g, np = ne * c.num_agents;
         int o = 0;
         auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
         kp.o.hdr = take(et * kp.HS);
-        kp.o.fcv = take(2 * et * nc);
-        kp.o.fci = take(2 * et * nc);
-        kp.o.act = take(et * c.num_agents);
-        kp.o.ord = take(et * c.num_agents);
+        kp.o.log = take(4 * et * c.num_agents);
+        kp.o.act = take(c.num_agents > 8 ? et * c.num_agents : 0);  // up to 8 agents: in registers
+        kp.o.ord = take(c.num_agents > 8 ? et * c.num_agents : 0);
         kp.o.rewm = take(et * c.num_agents);
         kp.o.tout = take(et * c.num_agents);
         kp.o.oterm = take(et * c.num_agents);
-        kp.o.flag = take(2 * et);
+        kp.o.flag = take(4 * et);
         kp.o.R = take(8 * et);
         kp.o.src = take(4 * et);
         kp.o.grid = take(ne * kp.GS);
         kp.o.img = take(np * img + 32);
         return o;
     };
+    // Measured on MI355X: about 32 environments per wavefront is the sweet spot between act-phase
+    // lane use and LDS-limited occupancy.
     int ne = 64 / c.num_agents;
     const int want_waves = 2048;
     while (ne > 1 && (c.num_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
     while (ne > 1 && lds_for(ne, 1) > 40 * 1024) --ne;
     int g = 1;
-    while ((g + 1) * ne <= 64 && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
+    while ((g + 1) * ne <= 32 && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
     if (const char *ev = getenv("MGRID_TILE")) {  // tuning override: "NE,G"
@@ -1028,9 +1394,10 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         delete h;
         return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", need);
     }
-    kp.NE = ne;
-    kp.G = g;
+    kp.geo |= static_cast<uint32_t>(ne) << 24;
+    kp.bits |= static_cast<uint32_t>(g) << 12;
     kp.magic_a = c.num_agents == 1 ? 0u : 0xFFFFFFFFu / c.num_agents + 1u;
+    kp.magic_nc = 0xFFFFFFFFu / (c.num_agents + 2) + 1u;
     kp.magic_per = kp.GS == 16 ? 0u : 0xFFFFFFFFu / (kp.GS / 16) + 1u;
     h->num_tiles = (c.num_envs + ne * g - 1) / (ne * g);
 
@@ -1067,7 +1434,7 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
     if (!h) return MG_EINVAL;
     if (!grids || !agents || n < 1) return fail(h, MG_EINVAL, "mg_upload_layouts: null pointer or n < 1");
     const KParams &kp = h->kp;
-    const int cells = kp.W * kp.H, A = kp.A;
+    const int cells = kp.W() * kp.H(), A = kp.A();
     std::vector<uint8_t> ph(static_cast<size_t>(n) * kp.HS, 0), pg(static_cast<size_t>(n) * kp.GS, 0);
     for (int l = 0; l < n; ++l) {
         uint8_t *hd = ph.data() + static_cast<size_t>(l) * kp.HS;
@@ -1083,17 +1450,26 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
         if (meta) memcpy(hd + H_META, meta + static_cast<size_t>(l) * 4, 4);
         const uint8_t *ar = agents + static_cast<size_t>(l) * A * 8;
         for (int k = 0; k < A; ++k) {
-            if (ar[8 * k + R_X] >= kp.W || ar[8 * k + R_Y] >= kp.H || ar[8 * k + R_DIR] > 3)
+            if (ar[8 * k + R_X] >= kp.W() || ar[8 * k + R_Y] >= kp.H() || ar[8 * k + R_DIR] > 3)
                 return fail(h, MG_EINVAL, "layout %d agent %d at (%d,%d) dir %d is outside the grid", l, k,
                             ar[8 * k + R_X], ar[8 * k + R_Y], ar[8 * k + R_DIR]);
             if (ar[8 * k + R_CT] > 15 || ar[8 * k + R_CC] > 127 || ar[8 * k + R_CS] > 15 || ar[8 * k + R_COLOR] > 127)
                 return fail(h, MG_EINVAL, "layout %d agent %d carries an out-of-range encoding", l, k);
         }
         memcpy(hd + H_ROWS, ar, static_cast<size_t>(A) * 8);
-        if (kp.kind == MG_KIND_REDBLUEDOORS && meta) {
+        // front cells of the start state (the step kernel keeps them current afterwards)
+        uint16_t *fc = reinterpret_cast<uint16_t *>(hd + kp.HFC);
+        static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
+        for (int k = 0; k < A; ++k) {
+            const int fx = ar[8 * k + R_X] + DX[ar[8 * k + R_DIR]], fy = ar[8 * k + R_Y] + DY[ar[8 * k + R_DIR]];
+            fc[k] = (fx >= 0 && fx < kp.W() && fy >= 0 && fy < kp.H()) ? gd[fx * kp.H() + fy] : 0;
+        }
+        if (kp.kind() == MG_KIND_REDBLUEDOORS && meta) {
             const uint8_t *m = meta + static_cast<size_t>(l) * 4;
-            if (m[0] >= kp.W || m[2] >= kp.W || m[1] >= kp.H || m[3] >= kp.H)
+            if (m[0] >= kp.W() || m[2] >= kp.W() || m[1] >= kp.H() || m[3] >= kp.H())
                 return fail(h, MG_EINVAL, "layout %d door position outside the grid", l);
+            fc[A] = gd[m[0] * kp.H() + m[1]];
+            fc[A + 1] = gd[m[2] * kp.H() + m[3]];
         }
     }
     MG_HIP(h, hipSetDevice(h->cfg.device));
@@ -1116,12 +1492,11 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
     if (h->num_layouts < 1) return fail(h, MG_ESTATE, "mg_reset: no layouts uploaded");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
-    kp.mode = MODE_RESET;
     kp.layout_idx = layout_idx_dev;
     kp.mask = mask_dev;
     kp.serial = h->reset_serial;  // 0: first reset, episode counters start at 0
     set_out(kp, out);
-    const int rc = launch_tile(h, kp, static_cast<hipStream_t>(stream));
+    const int rc = launch_tile<MODE_RESET>(h, kp, static_cast<hipStream_t>(stream));
     if (rc != MG_OK) return rc;
     h->reset_serial++;
     h->reset_done = true;
@@ -1136,12 +1511,11 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
         return fail(h, MG_ESTATE, "mg_step: autoreset needs uploaded layouts");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
-    kp.mode = MODE_STEP;
     kp.actions = actions_dev;
     kp.order = order_dev;
     kp.serial = h->step_serial;
     set_out(kp, out);
-    const int rc = launch_tile(h, kp, static_cast<hipStream_t>(stream));
+    const int rc = launch_tile<MODE_STEP>(h, kp, static_cast<hipStream_t>(stream));
     if (rc != MG_OK) return rc;
     h->step_serial++;
     h->launches++;
@@ -1153,16 +1527,15 @@ int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_gen_obs: call mg_reset (or mg_set_state) first");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
-    kp.mode = MODE_OBS;
     set_out(kp, out);
-    return launch_tile(h, kp, static_cast<hipStream_t>(stream));
+    return launch_tile<MODE_OBS>(h, kp, static_cast<hipStream_t>(stream));
 }
 
 int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *meta_dev, int32_t *steps_dev,
                  uint8_t *flags_dev, void *stream) {
     if (!h) return MG_EINVAL;
     MG_HIP(h, hipSetDevice(h->cfg.device));
-    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W * h->kp.H;
+    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W() * h->kp.H();
     const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 65535));
     hipLaunchKernelGGL(mg_get_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
                        grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);
@@ -1174,14 +1547,25 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
                  const int32_t *steps_dev, const uint8_t *flags_dev, void *stream) {
     if (!h) return MG_EINVAL;
     MG_HIP(h, hipSetDevice(h->cfg.device));
-    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W * h->kp.H;
+    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W() * h->kp.H();
     const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 65535));
     hipLaunchKernelGGL(mg_set_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
                        grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);
     MG_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(mg_refresh_front_kernel, dim3(std::min(4096, (h->kp.E * (h->kp.A() + 2) + 255) / 256)), dim3(256),
+                       0, static_cast<hipStream_t>(stream), h->kp);
+    MG_HIP(h, hipGetLastError());
     h->reset_done = true;
     return MG_OK;
 }
+
+#ifdef MGRID_EXPERIMENT
+int mg_dbg_buffer(MgHandle h, void *buf_dev, int *num_tiles) {
+    h->kp.dbg_buf = static_cast<unsigned long long *>(buf_dev);
+    if (num_tiles) *num_tiles = h->num_tiles;
+    return MG_OK;
+}
+#endif
 
 int mg_stats(MgHandle h, int64_t *stats_dev, void *stream) {
     if (!h) return MG_EINVAL;

@@ -20,6 +20,9 @@ CASES = {
     "odd3": ("MultiGrid-Empty-Random-6x6-v0", 3, dict(max_steps=30, success_termination_mode="all")),
     "odd5": ("MultiGrid-LockedHallway-2Rooms-v0", 5, dict(max_steps=30)),
     "single": ("MultiGrid-BlockedUnlockPickup-v0", 1, dict(max_steps=30)),
+    # more than 8 agents take the kernel's generic (LDS-array) act phase
+    "big12": ("MultiGrid-Empty-16x16-v0", 12, dict(max_steps=40, allow_agent_overlap=False, success_termination_mode="all")),
+    "big10": ("MultiGrid-LockedHallway-6Rooms-v0", 10, dict(max_steps=40)),
 }
 
 
@@ -107,7 +110,7 @@ def expected_layout(env_ids, episode, n_layouts, offset=0):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "odd3"])
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "odd3", "big10"])
 def test_autoreset_modes(case, mode):
     e, offset = 2500, 1000
     spec, pool, env, ora = make(case, e, autoreset=mode, env_id_offset=offset)
@@ -152,33 +155,38 @@ def test_autoreset_modes(case, mode):
     env.close()
 
 
-M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
-
-
-def mix64(z):
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    return z ^ (z >> np.uint64(31))
+def fmix32(h):
+    h = h ^ (h >> np.uint32(16))
+    h = h * np.uint32(0x85EBCA6B)
+    h = h ^ (h >> np.uint32(13))
+    h = h * np.uint32(0xC2B2AE35)
+    return h ^ (h >> np.uint32(16))
 
 
 def device_order(seed, gid, episode, step, a):
-    """The documented on-device permutation: Fisher-Yates driven by a splitmix64 stream keyed by
-    (seed, global environment index, episode, step)."""
+    """The documented on-device order: Fisher-Yates over 0..a-1, for k = a-1 .. 1 swapping entries k and
+    j = (field * (k + 1)) >> 16 with 16-bit fields taken low half first from fmix32(key + (q + 1) * 0x9E3779B9),
+    the key mixing (seed, global environment index, episode, step) through the murmur3 finalizer."""
     with np.errstate(over="ignore"):
-        gid, episode, step = (np.asarray(x).astype(np.uint64) for x in (gid, episode, step))
-        st = mix64(mix64(np.uint64(seed) ^ (gid << np.uint64(20))) ^ (episode << np.uint64(32)) ^ step)
+        gid, episode, step = (np.asarray(x).astype(np.uint32) for x in (gid, episode, step))
+        h = fmix32(np.uint32(seed & 0xFFFFFFFF) ^ gid)
+        h = fmix32(h ^ np.uint32(seed >> 32) ^ episode)
+        key = fmix32(h ^ step)
         order = np.tile(np.arange(a, dtype=np.uint8), (len(gid), 1))
         rows = np.arange(len(gid))
-        for k in range(a - 1, 0, -1):
-            st = mix64(st + np.uint64(0x9E3779B97F4A7C15))
-            j = (((st >> np.uint64(32)) * np.uint64(k + 1)) >> np.uint64(32)).astype(np.int64)
+        word = None
+        for f, k in enumerate(range(a - 1, 0, -1)):
+            if f % 2 == 0:
+                word = fmix32(key + np.uint32(f // 2 + 1) * np.uint32(0x9E3779B9))
+            field = (word >> np.uint32(16 * (f % 2))) & np.uint32(0xFFFF)
+            j = ((field * np.uint32(k + 1)) >> np.uint32(16)).astype(np.int64)
             tmp = order[rows, k].copy()
             order[rows, k] = order[rows, j]
             order[rows, j] = tmp
     return order
 
 
-@pytest.mark.parametrize("case", ["cfg4", "cfg5_nooverlap"])
+@pytest.mark.parametrize("case", ["cfg4", "cfg5_nooverlap", "big12"])
 def test_on_device_agent_order(case):
     e, offset, seed = 2048, 77, 99
     spec, pool, env, ora = make(case, e, autoreset=1, env_id_offset=offset, seed=seed)

@@ -1,0 +1,39 @@
+"""Per-phase clock stamps from the diagnostic build (tools/libmgrid_exp.so)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MGRID_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmgrid_exp.so")
+import numpy as np, torch
+from multigrid_amd import _lib, envs, layouts
+from multigrid_amd.batched import BatchedMultiGrid
+
+NAMES = {1: "hdr->LDS", 2: "act", 3: "resets+scalars", 4: "pass0: grid->LDS", 5: "pass0: patch+front cells", 6: "pass0: overlay",
+         7: "pass0: observe", 8: "pass0: copy-out", 9: "remaining passes", 10: "hdr->HBM"}
+
+def run(cfg, agents, e):
+    spec, gen = envs.make_spec(cfg, num_agents=agents)
+    env = BatchedMultiGrid(spec, e, device=0, autoreset=1, seed=1)
+    pool = layouts.make_pool(gen, 256)
+    env.upload_layouts(*pool[:3]); env.reset()
+    L = _lib.lib()
+    nt = ctypes.c_int()
+    buf = torch.zeros((1 << 16, 32), dtype=torch.int64, device=env.device)
+    acts = torch.randint(0, 7, (8, e, agents), device=env.device, dtype=torch.uint8)
+    for t in range(30): env.step(acts[t % 8])
+    L.mg_dbg_buffer(env._h, ctypes.c_void_p(buf.data_ptr()), ctypes.byref(nt))
+    env.step(acts[0]); torch.cuda.synchronize()
+    b = buf[:nt.value].cpu().numpy().astype(np.float64)
+    total = (b[:, 10] - b[:, 0]).mean()
+    print(f"{cfg} A={agents} E={e} tiles={nt.value} tile={os.environ.get('MGRID_TILE','auto')}: mean wave lifetime {total:.0f} clk")
+    prev = 0
+    for k in range(1, 11):
+        d = (b[:, k] - b[:, prev]).mean()
+        print(f"   {NAMES[k]:28s} {d:9.0f} clk  {100*d/total:5.1f}%")
+        prev = k
+    span = b[:, 10].max() - b[:, 0].min()
+    print(f"   kernel span {span:.0f} clk")
+    env.close()
+
+if __name__ == "__main__":
+    cases = (("MultiGrid-Empty-16x16-v0", 8, 131072), ("MultiGrid-BlockedUnlockPickup-v0", 2, 65536), ("MultiGrid-LockedHallway-4Rooms-v0", 4, 65536), ("MultiGrid-RedBlueDoors-8x8-v0", 2, 4096))
+    for i in [int(x) for x in os.environ.get("CASES", "0").split(",")]:
+        run(*cases[i])
