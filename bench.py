@@ -45,6 +45,22 @@ def algorithmic_bytes_per_env_step(spec) -> int:
     return 156 * a + 2 * (8 * a + 8) + 3 * w * h + 3 * a
 
 
+def measured_traffic(cfg_id, num_envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), when one
+    matches this workload; the counters cannot be read from inside this process."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        name = CONFIGS[cfg_id][0]
+        if name in d.get("workload", "") and f"{num_envs} envs" in d.get("workload", ""):
+            best = d.get("hbm_bytes_per_launch")
+    return best
+
+
 def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False):
     import numpy as np
     import torch
@@ -209,7 +225,8 @@ def main():
                    "grid": [spec["width"], spec["height"]], "steps_per_launch": 1,
                    "launch": "hip_graph" if args.graph else "eager", "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, num_envs),
+                     "traffic_unit": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from profiles/",
                      "kernel": "mg_tile_kernel", "algorithmic_bytes_per_env_step": bytes_step,
                      "launch_us": launch_s * 1e6},
         "episode_stats": {"episodes": int(r["stats"][0]), "mean_length": float(r["stats"][1]) / max(1, int(r["stats"][0])),

@@ -1,0 +1,176 @@
+"""The reference's Python surface over the batched HIP simulator.
+
+``MultiGridEnv`` here is a drop-in for one ``multigrid.base.MultiGridEnv`` instance
+(multigrid/base.py:37): ``reset(seed) -> (obs, infos)`` and
+``step({agent: action}) -> (obs, rewards, terminations, truncations, infos)`` with the same
+dict-of-dict layout (integer agent keys, ``{"image", "direction", "mission"}`` observations),
+``is_done()``, ``gen_obs()``, ``step_count`` / ``max_steps`` / ``num_agents``.  It drives a
+``BatchedMultiGrid`` of one environment, draws layouts with the host-side generators and the
+agent order from ``np_random`` exactly where the reference does, so the same generators give
+the same trajectory.  ``RLlibWrapper`` and ``PettingZooWrapper`` mirror
+multigrid/rllib/__init__.py:47-76 and multigrid/pettingzoo/__init__.py:35-70 by duck typing
+(neither ray nor pettingzoo is required).  For throughput use ``BatchedMultiGrid`` directly.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, envs
+from .batched import BatchedMultiGrid
+from .constants import COLOR_NAMES
+
+
+class Mission(str):
+    """Mission text; like the reference's ``Mission`` (multigrid/core/mission.py:8) it exposes ``.string``."""
+
+    @property
+    def string(self) -> str:
+        return str(self)
+
+
+class MultiGridEnv:
+    metadata = {"render_modes": [], "render_fps": 20}
+
+    def __init__(self, name: str, agents: Optional[int] = None, teams: Optional[Dict[str, int]] = None,
+                 agent_view_size: int = 7, device: int | str = 0, layout_rng: Optional[np.random.Generator] = None,
+                 **kwargs):
+        self.name = name
+        self.spec, self._gen = envs.make_spec(name, num_agents=agents, teams=teams,
+                                              agent_view_size=agent_view_size, **kwargs)
+        self.teams = teams if teams is not None else envs.default_teams(self.spec["num_agents"])
+        self.num_agents = self.spec["num_agents"]
+        self.max_steps = self.spec["max_steps"]
+        self.width, self.height = self.spec["width"], self.spec["height"]
+        self._sim = BatchedMultiGrid(self.spec, 1, device=device, autoreset=_lib.AUTORESET_NONE)
+        # RandomMixin keeps the generator that existed at construction time (multigrid/base.py:153);
+        # gym.Env.np_random is the same object until reset(seed) replaces it.
+        self._np_random = layout_rng if layout_rng is not None else np.random.default_rng()
+        self._layout_rng = self._np_random
+        self.mission = Mission(self.spec["mission"])
+        self.step_count = 0
+        self._terminated = np.zeros(self.num_agents, dtype=bool)
+        self.agent_names = []
+        for team, n in self.teams.items():
+            self.agent_names += [f"{team}_{i}" for i in range(n)]
+
+    # -- gym.Env ------------------------------------------------------------------------------------
+    @property
+    def np_random(self) -> np.random.Generator:
+        return self._np_random
+
+    def reset(self, seed: Optional[int] = None, **kwargs):
+        """multigrid/base.py:310-362."""
+        if seed is not None:
+            self._np_random = np.random.default_rng(seed)
+        grid, agents, meta, mission = self._gen(mixin_rng=self._layout_rng, env_rng=self._np_random)
+        self.mission = Mission(mission)
+        self._sim.upload_layouts(grid[None], agents[None], meta[None])
+        out = self._sim.reset(layout_idx=np.zeros(1, np.int32))
+        self.step_count = 0
+        self._terminated[:] = False
+        return self._obs_dict(out), defaultdict(dict)
+
+    def step(self, actions: Dict[int, int]):
+        """multigrid/base.py:364-408 plus the environment's own step hook."""
+        a = self.num_agents
+        acts = np.array([[int(actions[i]) for i in range(a)]], dtype=np.uint8)
+        if a == 1:  # base.py:457-461
+            order = np.zeros((1, 1), dtype=np.uint8)
+        else:
+            order = self._np_random.random(size=a).argsort()[None].astype(np.uint8)
+        out = self._sim.step(acts, order)
+        self.step_count += 1
+        rew = out.reward[0].cpu().numpy().astype(np.float64)
+        term = out.terminated[0].cpu().numpy().astype(bool)
+        trunc = out.truncated[0].cpu().numpy().astype(bool)
+        st = self._sim.get_state()
+        self._terminated = st["agents"][0, :, 3].cpu().numpy().astype(bool)
+        rewards = {i: (float(rew[i]) if rew[i] != 0 else 0) for i in range(a)}
+        terminations = {i: np.bool_(term[i]) for i in range(a)}
+        truncations = {i: bool(trunc[i]) for i in range(a)}
+        return self._obs_dict(out), rewards, terminations, truncations, defaultdict(dict)
+
+    def gen_obs(self):
+        """multigrid/base.py:410-438."""
+        return self._obs_dict(self._sim.gen_obs())
+
+    def is_done(self) -> bool:
+        """multigrid/base.py:587-596."""
+        return self.step_count >= self.max_steps or bool(self._terminated.all())
+
+    def close(self):
+        self._sim.close()
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _obs_dict(self, out):
+        img = out.image[0].cpu().numpy().astype(np.int64)
+        direction = out.direction[0].cpu().numpy().astype(np.int64)
+        return {i: {"image": img[i], "direction": direction[i], "mission": self.mission}
+                for i in range(self.num_agents)}
+
+    @property
+    def agent_states(self) -> np.ndarray:
+        """(A, 9) rows in the reference's column order (multigrid/core/agent.py:266-275)."""
+        rows = self._sim.get_state()["agents"][0].cpu().numpy().astype(np.int64)
+        out = np.zeros((self.num_agents, 9), dtype=np.int64)
+        out[:, 0], out[:, 1], out[:, 2] = 10, rows[:, 7], rows[:, 2]
+        out[:, 3], out[:, 4], out[:, 5] = rows[:, 0], rows[:, 1], rows[:, 3]
+        out[:, 6:9] = rows[:, 4:7]
+        return out
+
+    @property
+    def grid_state(self) -> np.ndarray:
+        """(W, H, 3) ``grid.state`` (multigrid/core/grid.py:53)."""
+        return self._sim.get_state()["grid"][0].cpu().numpy().astype(np.int64)
+
+
+class RLlibWrapper:
+    """``MultiAgentEnv`` view: ``__all__`` keys added to terminations and truncations
+    (multigrid/rllib/__init__.py:71-76)."""
+
+    def __init__(self, env: MultiGridEnv):
+        self.env = env
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def get_agent_ids(self):
+        return set(range(self.env.num_agents))
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def step(self, actions):
+        obs, rewards, terminations, truncations, infos = self.env.step(actions)
+        terminations["__all__"] = all(terminations.values())
+        truncations["__all__"] = all(truncations.values())
+        return obs, rewards, terminations, truncations, infos
+
+
+class PettingZooWrapper:
+    """``ParallelEnv`` view (multigrid/pettingzoo/__init__.py:35-70)."""
+
+    def __init__(self, env: MultiGridEnv):
+        self.env = env
+        self.reset = env.reset
+        self.step = env.step
+        self.close = env.close
+
+    @property
+    def agents(self):
+        if self.env.is_done():
+            return []
+        return [i for i in range(self.env.num_agents) if not self.env._terminated[i]]
+
+    @property
+    def possible_agents(self):
+        return list(range(self.env.num_agents))
+
+
+def make(name: str, **kwargs) -> MultiGridEnv:
+    """``gym.make``-style constructor over the registry (multigrid/envs/__init__.py:43-625)."""
+    return MultiGridEnv(name, **kwargs)

@@ -1,0 +1,52 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/mgrid.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mgrid.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    from multigrid_amd import _lib
+    assert set(declared_symbols()) == set(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from multigrid_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmgrid_hip.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.mg_abi_version() == 1
+
+
+def test_bad_arguments_fail_without_a_gpu():
+    from multigrid_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libmgrid_hip.so not built")
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    cfg = _lib.MgConfig(kind=0, width=8, height=8, num_agents=2, view_size=4, max_steps=10, num_envs=4)
+    assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1  # MG_EINVAL: view size must be 3, 5 or 7
+    assert b"view_size" in L.mg_last_error(None)
+    cfg = _lib.MgConfig(kind=3, width=13, height=9, num_agents=2, view_size=7, max_steps=10, num_envs=4, num_rooms=8)
+    assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"LockedHallway" in L.mg_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multigrid_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
