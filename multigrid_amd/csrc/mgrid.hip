@@ -532,6 +532,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 #pragma unroll
     for (int k = 0; k < 8; ++k) termw |= static_cast<uint64_t>(rows[8 * min(k, A - 1) + R_TERM]) << (8 * k);
     termw &= ones * 0xFF;
+#pragma unroll 1
 
     for (int n = 0; n < A; ++n) {  // base.py:464
         const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
@@ -608,11 +609,13 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     bool term_all = false;  // a hook terminated every agent
     uint64_t term_some = 0; // a hook terminated these agents (mode "all")
     if (rbd) {  // redbluedoors.py:176-185
+#pragma unroll 1
         for (int i = 0; i < A; ++i) {
             if (byte_of(actw, i) != ACT_TOGGLE) continue;
             if (front_xy(*reinterpret_cast<const uint32_t *>(rows + 8 * i)) != blue_xy) continue;
             uint32_t wb = fcv[A + 1], wr = fcv[A];
             const uint32_t cb = (blue_xy & 0xFF) * H + (blue_xy >> 8), cr = (red_xy & 0xFF) * H + (red_xy >> 8);
+#pragma unroll 1
             for (int j = 0; j < nlog; ++j) {
                 const uint32_t e = log[j];
                 if ((e & 0xFFFF) == cb) wb = e >> 16;
@@ -630,6 +633,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             }
         }
     } else if (p.kind() == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
+#pragma unroll 1
         for (int i = 0; i < A; ++i) {
             if (rows[8 * i + R_CT] != T_BOX) continue;
             term_all = true;  // this environment always terminates "any" (blockedunlockpickup.py:128)
@@ -637,15 +641,18 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         }
         if (!p.succ_any() && term_all) {  // not reachable through the registry; keeps base.py:553-556 exact
             term_all = false;
+#pragma unroll 1
             for (int i = 0; i < A; ++i)
                 if (rows[8 * i + R_CT] == T_BOX) term_some |= 1ull << (8 * i);
         }
     } else if (p.kind() == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
+#pragma unroll 1
         for (int i = 0; i < A; ++i) {
             if (byte_of(actw, i) != ACT_TOGGLE) continue;
             const uint32_t ci = front_index(p, *reinterpret_cast<const uint32_t *>(rows + 8 * i));
             if (ci == FC_NONE) continue;
             uint32_t w = fcv[i];
+#pragma unroll 1
             for (int j = 0; j < nlog; ++j) {
                 const uint32_t e = log[j];
                 if ((e & 0xFFFF) == ci) w = e >> 16;
@@ -660,6 +667,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     if (term_all) term_some = ones;
     if (term_some) {  // hooks set both the agents' own flags and the returned dict
         toutw |= term_some;
+#pragma unroll 1
         for (int k = 0; k < A; ++k)
             if (byte_of(term_some, k)) rows[8 * k + R_TERM] = 1;
     }
@@ -692,6 +700,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset) {
         uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+#pragma unroll 1
         for (int j = 0; j < nlog; ++j) {
             const uint32_t e = log[j];
             gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
@@ -821,11 +830,16 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
 // Diagnostic build only: drain memory, read the shader clock, keep it in a buffer of its own.
 #define MG_STAMP(k)                                                                        \
     do {                                                                                   \
-        if (p.dbg_buf) {                                                                   \
+        if (p.dbg_buf && !(p.dbg & 16)) {                                                  \
             __builtin_amdgcn_s_waitcnt(0);                                                 \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
             if (threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + (k)] = t_; \
         }                                                                                  \
+    } while (0)
+// Light stamp: no drain, so the pipeline keeps running; accumulates a time difference instead.
+#define MG_TICK(var)                                                                       \
+    do {                                                                                   \
+        if (p.dbg_buf && (p.dbg & 16)) var = __builtin_amdgcn_s_memtime();                 \
     } while (0)
 #else
 #define MG_STAMP(k) do { } while (0)
@@ -837,7 +851,7 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
 // the whole launch; grids are brought in NE environments ("sub-tile", NE * A <= 64 agent lanes)
 // at a time for the observation passes.
 
-template <int V, bool SEE, int MODE>
+template <int V, bool SEE, int MODE, bool SMALLA>
 __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int IMG = 3 * V * V;  // bytes per agent image
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 
     MG_STAMP(0);
     // up to 8 agents: each environment's action and order bytes ride in two registers of its act lane
-    const bool small = A <= 8;
+    constexpr bool small = SMALLA;  // A <= 8, chosen by the host
     uint64_t actw = 0, ordw = 0;
     if (MODE == MODE_STEP && small && lane < net) {
         actw = load_bytes(p.actions + static_cast<size_t>(e0 + lane) * A, A);
@@ -956,7 +970,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     // ---- act ---------------------------------------------------------------------------------------
     if (MODE == MODE_STEP) {
         if (lane < net) {
-            if (small)
+            if constexpr (small)
                 act_env_small(p, lds, lane, e0 + lane, actw, ordw);
             else
                 act_env(p, lds, lane, e0 + lane);
@@ -1008,6 +1022,10 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #endif
             if (has_next) issue(s0 + NE);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef MGRID_EXPERIMENT
+            unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+            MG_TICK(tk0);
+#endif
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
             const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
@@ -1053,9 +1071,19 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 const uint2 r = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
                 const uint32_t xy = r.x & 0xFFFF;
                 bool top = true;
-                for (int k = my_agent + 1; k < A; ++k) {
-                    const uint32_t rk = *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * k);
-                    top &= ((rk & 0xFFFF) != xy) | (lds[p.o.oterm + (s0 + my_slot) * A + k] != 0);
+                if constexpr (small) {  // all rows in flight at once
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) {
+                        const int kk = min(k, A - 1);
+                        const uint32_t rk = *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * kk);
+                        const bool hides = (rk & 0xFFFF) == xy && lds[p.o.oterm + (s0 + my_slot) * A + kk] == 0;
+                        top &= !(hides && kk > my_agent);
+                    }
+                } else {
+                    for (int k = my_agent + 1; k < A; ++k) {
+                        const uint32_t rk = *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * k);
+                        top &= ((rk & 0xFFFF) != xy) | (lds[p.o.oterm + (s0 + my_slot) * A + k] != 0);
+                    }
                 }
                 const unsigned x = xy & 0xFF, y = xy >> 8;
                 if (top && x < static_cast<unsigned>(p.W()) && y < static_cast<unsigned>(p.H()))
@@ -1076,9 +1104,14 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             wave_sync();
             // the next sub-tile's grids may now replace this one's
 #ifdef MGRID_EXPERIMENT
+            MG_TICK(tk1);
             if (!(p.dbg & 4))
 #endif
             if (has_next) commit(s0 + NE);
+#ifdef MGRID_EXPERIMENT
+            if (p.dbg_buf && (p.dbg & 16)) { __builtin_amdgcn_s_waitcnt(0xC07F); }
+            MG_TICK(tk2);
+#endif
 
             if (s0 == 0) MG_STAMP(7);
             uint8_t *gdst = p.image + out_base - shift;
@@ -1087,7 +1120,18 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 2))
 #endif
-            if (want_img)
+            if (want_img && all_active && shift == 0 && (total & 15) == 0) {
+                // whole, aligned stream: all LDS reads first, then all stores
+                constexpr int MAXIT = (64 * IMG + 1023) / 1024;
+                const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.img);
+                uint4 *dst16 = reinterpret_cast<uint4 *>(gdst);
+                uint4 ob[MAXIT];
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, nchunk - 1)];
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it)
+                    if (it * 64 + lane < nchunk) dst16[it * 64 + lane] = ob[it];
+            } else if (want_img) {
             for (int c = lane; c < nchunk; c += 64) {
                 const int b0 = 16 * c;
                 if (all_active && b0 >= shift && b0 + 16 <= total) {
@@ -1100,8 +1144,19 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                     }
                 }
             }
+            }
             wave_sync();
             if (s0 == 0) MG_STAMP(8);
+#ifdef MGRID_EXPERIMENT
+            MG_TICK(tk3);
+            if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
+                unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 16;
+                d[0] += tk1 - tk0;  // compute (patch .. observe)
+                d[1] += tk2 - tk1;  // commit (wait for the prefetched grids, write them to LDS)
+                d[2] += tk3 - tk2;  // copy-out (LDS reads + store issue)
+                d[3] += 1;
+            }
+#endif
         }
     }
 
@@ -1273,10 +1328,15 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 template <int V, int MODE>
 void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
-    if (h->cfg.see_through_walls)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE>), grid, block, h->lds_bytes, s, kp);
+    const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
+    if (see && small)
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true>), grid, block, h->lds_bytes, s, kp);
+    else if (see)
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false>), grid, block, h->lds_bytes, s, kp);
+    else if (small)
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true>), grid, block, h->lds_bytes, s, kp);
     else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false>), grid, block, h->lds_bytes, s, kp);
 }
 
 template <int MODE>

@@ -20,7 +20,9 @@ def run(cfg, agents, e):
     acts = torch.randint(0, 7, (8, e, agents), device=env.device, dtype=torch.uint8)
     for t in range(30): env.step(acts[t % 8])
     L.mg_dbg_buffer(env._h, ctypes.c_void_p(buf.data_ptr()), ctypes.byref(nt))
-    env.step(acts[0]); torch.cuda.synchronize()
+    if os.environ.get('GENOBS'): env.gen_obs()
+    else: env.step(acts[0])
+    torch.cuda.synchronize()
     b = buf[:nt.value].cpu().numpy().astype(np.float64)
     total = (b[:, 10] - b[:, 0]).mean()
     print(f"{cfg} A={agents} E={e} tiles={nt.value} tile={os.environ.get('MGRID_TILE','auto')}: mean wave lifetime {total:.0f} clk")
@@ -29,8 +31,9 @@ def run(cfg, agents, e):
         d = (b[:, k] - b[:, prev]).mean()
         print(f"   {NAMES[k]:28s} {d:9.0f} clk  {100*d/total:5.1f}%")
         prev = k
-    span = b[:, 10].max() - b[:, 0].min()
-    print(f"   kernel span {span:.0f} clk")
+    if int(os.environ.get("MGRID_DBG", "0")) & 16:
+        n = b[:, 19].sum()
+        print(f"   light ticks per pass: compute {b[:,16].sum()/n:.0f}  commit {b[:,17].sum()/n:.0f}  copy-out {b[:,18].sum()/n:.0f} clk ({n:.0f} passes)")
     env.close()
 
 if __name__ == "__main__":
