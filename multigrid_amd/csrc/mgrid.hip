@@ -911,7 +911,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         return reinterpret_cast<const uint4 *>(base) + (i - sub * per);
     };
 #define MG_ISSUE1(c, r) r = *grid_src(s0_, min((c) * 64 + lane, n16_ - 1));
-#define MG_COMMIT1(c, r) if ((c) * 64 + lane < n16_) dg_[(c) * 64 + lane] = r;
+#define MG_COMMIT1(c, r) if ((c) * 64 + lane < n16_) dg_[(c) * 64 + lane + udiv((c) * 64 + lane, p.magic_per)] = r;
 #define MG_EACH(OP) OP(0, gb0) OP(1, gb1) OP(2, gb2) OP(3, gb3) OP(4, gb4) OP(5, gb5) OP(6, gb6) OP(7, gb7)
     auto issue = [&](int s0_) {
         const int n16_ = min(NE, net - s0_) * per;
@@ -921,7 +921,8 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         const int n16_ = min(NE, net - s0_) * per;
         uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
         MG_EACH(MG_COMMIT1)
-        for (int i = 512 + lane; i < n16_; i += 64) dg_[i] = *grid_src(s0_, i);  // grids beyond 8 KiB per sub-tile
+        for (int i = 512 + lane; i < n16_; i += 64)  // grids beyond 8 KiB per sub-tile
+            dg_[i + udiv(i, p.magic_per)] = *grid_src(s0_, i);
     };
 #undef MG_ISSUE1
 #undef MG_COMMIT1
@@ -1029,12 +1030,12 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
             const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
-            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + my_slot * p.GS);
+            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + my_slot * (p.GS + 16));
             if (MODE == MODE_STEP) {
                 // cells changed by this step, replayed in order (one lane per environment)
                 if (lane < ns && ((sub_mask >> lane) & 1)) {
                     const uint32_t *log = reinterpret_cast<const uint32_t *>(lds + p.o.log) + (s0 + lane) * A;
-                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + lane * p.GS);
+                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + lane * (p.GS + 16));
                     const int n = lds[p.o.flag + 4 * (s0 + lane) + 2];
                     for (int j = 0; j < n; ++j) {
                         const uint32_t e = log[j];
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 if (p.kind() == MG_KIND_REDBLUEDOORS && lane < ns && ((sub_mask >> lane) & 1)) {
                     uint8_t *h = lds + p.o.hdr + (s0 + lane) * p.HS;
                     const uint32_t meta = *reinterpret_cast<const uint32_t *>(h + H_META);
-                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + lane * p.GS);
+                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + lane * (p.GS + 16));
                     const uint32_t last = static_cast<uint32_t>(p.W() * p.H() - 1);
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A] = g[min((meta & 0xFF) * p.H() + ((meta >> 8) & 0xFF), last)];
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A + 1] = g[min(((meta >> 16) & 0xFF) * p.H() + (meta >> 24), last)];
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             if (!(p.dbg & 1))
 #endif
             if (want_img && mine)
-                observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * p.GS,
+                observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16),
                                       lds + p.o.img + shift + lane * IMG);
             wave_sync();
             // the next sub-tile's grids may now replace this one's
@@ -1132,7 +1133,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 for (int it = 0; it < MAXIT; ++it)
                     if (it * 64 + lane < nchunk) dst16[it * 64 + lane] = ob[it];
             } else if (want_img) {
-            for (int c = lane; c < nchunk; c += 64) {
+              for (int c = lane; c < nchunk; c += 64) {
                 const int b0 = 16 * c;
                 if (all_active && b0 >= shift && b0 + 16 <= total) {
                     *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o.img + b0);
@@ -1423,7 +1424,7 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         kp.o.flag = take(4 * et);
         kp.o.R = take(8 * et);
         kp.o.src = take(4 * et);
-        kp.o.grid = take(ne * kp.GS);
+        kp.o.grid = take(ne * (kp.GS + 16));  // 16 bytes between grids spread them over the LDS banks
         kp.o.img = take(np * img + 32);
         return o;
     };

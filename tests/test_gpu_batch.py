@@ -292,3 +292,35 @@ def test_baseline_sizes(case, e):
         compare(out, (img, direction, rew, term, trunc), f"{case} E={e} step {t}")
     compare_state(env, ora, f"{case} E={e} final")
     env.close()
+
+
+@pytest.mark.parametrize("case,tile", [("cfg5", "2,3"), ("wide2", "32,1"), ("wide2", "20,2"), ("cfg4", "16,4"),
+                                       ("single", "64,1"), ("odd3", "7,2")])
+def test_explicit_tile_shapes(case, tile, monkeypatch):
+    """Tile shapes the size heuristic does not pick for small batches, among them sub-tiles whose grids
+    exceed the 8 KiB the prefetch registers hold (wide2)."""
+    table = dict(CASES, wide2=("MultiGrid-Empty-16x16-v0", 2, dict(max_steps=40)))
+    monkeypatch.setenv("MGRID_TILE", tile)
+    e = 1111
+    spec, pool, env, ora = make(case, e, table=table, autoreset=2)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(5)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    out = env.reset()
+    idx = expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    np.testing.assert_array_equal(out.image.cpu().numpy(), ora.gen_obs())
+    for t in range(60):
+        actions, order = rand_inputs(rng, e, a)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        compare(out, res, f"{case} tile {tile} step {t}")
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+    compare_state(env, ora, f"{case} tile {tile} final")
+    env.close()
