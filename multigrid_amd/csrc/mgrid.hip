@@ -897,32 +897,48 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     wave_sync();
     const int per = p.GS / 16;
     const bool want_img = p.image != nullptr;
+#ifdef MGRID_EXPERIMENT
+    const bool passes = (want_img || MODE == MODE_STEP) && !(p.dbg & 32);
+#else
     const bool passes = want_img || MODE == MODE_STEP;
+#endif
     // Grid blocks travel HBM -> registers -> LDS one sub-tile ahead: the loads for sub-tile g + 1
     // are issued before sub-tile g is computed and land in LDS after its observation has read
     // the previous grid, just before its image is stored; so neither the load latency nor the
-    // completion of the image stores sits on the critical path.
+    // completion of the image stores sits on the critical path.  A sub-tile's grids are one
+    // contiguous block of the state array, so the loads need no per-lane address arithmetic
+    // beyond lane * 16; environments restarted in this launch are patched in from the pool
+    // afterwards (fixup), which is rare enough to stay a plain loop.
     uint4 gb0, gb1, gb2, gb3, gb4, gb5, gb6, gb7;
-    auto grid_src = [&](int s0, int i) -> const uint4 * {
-        const int sub = udiv(i, p.magic_per);
-        const int src = lsrc[s0 + sub];
-        const uint8_t *base = src < 0 ? p.grid + static_cast<size_t>(e0 + s0 + sub) * p.GS
-                      : p.pool_grid + static_cast<size_t>(src) * p.GS;  // just reset: from the pool
-        return reinterpret_cast<const uint4 *>(base) + (i - sub * per);
-    };
-#define MG_ISSUE1(c, r) r = *grid_src(s0_, min((c) * 64 + lane, n16_ - 1));
-#define MG_COMMIT1(c, r) if ((c) * 64 + lane < n16_) dg_[(c) * 64 + lane + udiv((c) * 64 + lane, p.magic_per)] = r;
+#define MG_ISSUE1(c, r) if ((c) * 64 < n16_) r = src_[min((c) * 64 + lane, n16_ - 1)];
+#define MG_COMMIT1(c, r) \
+    if ((c) * 64 < n16_ && (c) * 64 + lane < n16_) dg_[(c) * 64 + lane + udiv((c) * 64 + lane, p.magic_per)] = r;
 #define MG_EACH(OP) OP(0, gb0) OP(1, gb1) OP(2, gb2) OP(3, gb3) OP(4, gb4) OP(5, gb5) OP(6, gb6) OP(7, gb7)
     auto issue = [&](int s0_) {
         const int n16_ = min(NE, net - s0_) * per;
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0 + s0_) * p.GS);
         MG_EACH(MG_ISSUE1)
     };
     auto commit = [&](int s0_) {
-        const int n16_ = min(NE, net - s0_) * per;
+        const int ns_ = min(NE, net - s0_);
+        const int n16_ = ns_ * per;
         uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
         MG_EACH(MG_COMMIT1)
-        for (int i = 512 + lane; i < n16_; i += 64)  // grids beyond 8 KiB per sub-tile
-            dg_[i + udiv(i, p.magic_per)] = *grid_src(s0_, i);
+        if (n16_ > 512) {  // grids beyond 8 KiB per sub-tile
+            const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0 + s0_) * p.GS);
+#pragma unroll 1
+            for (int i = 512 + lane; i < n16_; i += 64) dg_[i + udiv(i, p.magic_per)] = src_[i];
+        }
+        if (MODE != MODE_OBS && __ballot(lane < ns_ && lsrc[s0_ + lane] >= 0)) {
+            // environments restarted in this launch: their grid comes from the layout pool
+#pragma unroll 1
+            for (int i = lane; i < n16_; i += 64) {
+                const int sub = udiv(i, p.magic_per);
+                const int src = lsrc[s0_ + sub];
+                if (src >= 0)
+                    dg_[i + sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
+            }
+        }
     };
 #undef MG_ISSUE1
 #undef MG_COMMIT1
@@ -1004,13 +1020,8 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     if (passes) {
         const int my_slot = udiv(lane, p.magic_a);  // environment (within the sub-tile) of this lane's agent
         const int my_agent = lane - my_slot * A;
-        {
-            // re-fetch the first sub-tile if the reset path changed where any of its grids come from
-            bool moved = false;
-            for (int k = 0; k < min(NE, net); ++k) moved |= lsrc[k] >= 0;
-            if (moved || MODE == MODE_RESET) issue(0);
-            commit(0);
-        }
+        if (MODE == MODE_RESET) issue(0);
+        commit(0);
         wave_sync();
         for (int s0 = 0; s0 < net; s0 += NE) {
             const int ns = min(NE, net - s0);
@@ -1101,7 +1112,11 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #endif
             if (want_img && mine)
                 observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16),
+#ifdef MGRID_EXPERIMENT
+                                      lds + p.o.img + shift + (lane % (64 / (1 + ((p.dbg >> 8) & 3)))) * IMG);
+#else
                                       lds + p.o.img + shift + lane * IMG);
+#endif
             wave_sync();
             // the next sub-tile's grids may now replace this one's
 #ifdef MGRID_EXPERIMENT
@@ -1128,7 +1143,11 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 uint4 *dst16 = reinterpret_cast<uint4 *>(gdst);
                 uint4 ob[MAXIT];
 #pragma unroll
+#ifdef MGRID_EXPERIMENT
+                for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, nchunk - 1) % (nchunk / (1 + ((p.dbg >> 8) & 3)))];
+#else
                 for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, nchunk - 1)];
+#endif
 #pragma unroll
                 for (int it = 0; it < MAXIT; ++it)
                     if (it * 64 + lane < nchunk) dst16[it * 64 + lane] = ob[it];
@@ -1448,7 +1467,12 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     h->lds_bytes = static_cast<size_t>(lds_for(ne, g));
 #ifdef MGRID_EXPERIMENT
     if (const char *ev = getenv("MGRID_LDS_PAD")) h->lds_bytes += static_cast<size_t>(atoi(ev));
-    if (const char *ev = getenv("MGRID_DBG")) kp.dbg = atoi(ev);
+    if (const char *ev = getenv("MGRID_DBG")) {
+        kp.dbg = atoi(ev);
+        if (kp.dbg & 32) h->lds_bytes = static_cast<size_t>(kp.o.grid);  // act phase alone
+        const int k = 1 + ((kp.dbg >> 8) & 3);  // wrong results on purpose: image staging shared by k lane groups
+        h->lds_bytes -= static_cast<size_t>(round_up((ne * c.num_agents * img) * (k - 1) / k, 16));
+    }
 #endif
     if (h->lds_bytes > 64 * 1024) {
         const size_t need = h->lds_bytes;
