@@ -56,6 +56,14 @@ constexpr uint32_t LAYOUT_STRIDE = 7919;  // layout of episode k of env g: (g + 
 
 constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 
+#ifndef MG_STAGE_LANES
+#define MG_STAGE_LANES 16
+#endif
+// With few agents per environment the in-order replay (one lane per environment) is cheaper than the
+// lane-per-agent pass plus its bookkeeping; measured crossover on MI355X.
+constexpr int PARALLEL_ACT_MIN_AGENTS = 6;
+constexpr int STAGE_LANES = MG_STAGE_LANES;  // agents whose images share the LDS staging buffer; a multiple of 16
+
 struct LdsMap {
     int hdr;    // [ET][HS]      header blocks of the wave's environments
     int log;    // [ET][A]   u32 cells written by this step, in order: cell index | packed cell << 16
@@ -68,7 +76,7 @@ struct LdsMap {
     int R;      // [ET]      f64 _reward() of this step
     int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
     int grid;   // [NE][GS]      grids of the sub-tile being observed
-    int img;    // [NE*A][3VV]+32 image bytes of the sub-tile, in output order
+    int img;    // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order
 };
 
 struct KParams {
@@ -204,6 +212,91 @@ __device__ __forceinline__ uint32_t front_index(const KParams &p, uint32_t r) {
     return (fx < static_cast<uint32_t>(p.W()) && fy < static_cast<uint32_t>(p.H())) ? fx * p.H() + fy : FC_NONE;
 }
 
+// ---- one agent's action ---------------------------------------------------------------------------
+//
+// The body of the loop multigrid/base.py:464-528 for one agent, split where it asks whether another
+// agent stands on the cell in front (base.py:485,512): eval_action() decides everything that depends
+// only on the agent and that cell, finish_action() the rest.  Lane-varying conditions are kept as
+// bits of one register rather than as booleans.
+enum : uint32_t {
+    EV_ALIVE = 1u, EV_ONCELL = 2u, EV_FWD = 4u, EV_DROP = 8u, EV_PK = 16u, EV_UNLOCK = 32u, EV_FLIP = 64u,
+    EV_BOX = 128u, EV_BLUE = 256u, EV_GOAL = 512u, EV_TERM = 1024u, EV_WRITE = 2048u,
+    EV_MAY_WRITE = EV_DROP | EV_PK | EV_UNLOCK | EV_FLIP | EV_BOX,
+};
+
+struct ActEval {
+    uint2 r;        // the agent's row after the action
+    uint32_t fxy;   // position in front, x | y << 8
+    uint32_t ci;    // its grid index (meaningful with EV_ONCELL)
+    uint32_t w;     // value of that cell when the agent acts
+    uint32_t nv;    // value the cell takes (with EV_WRITE)
+    uint32_t bits;  // EV_*
+};
+
+__device__ __forceinline__ ActEval eval_action(const KParams &p, uint2 r0, uint32_t w, int act, uint32_t flags,
+                                               uint32_t blue_xy) {
+    ActEval e;
+    const bool alive = (r0.x >> 24) == 0;  // base.py:467
+    const int dir = (r0.x >> 16) & 3;
+    // left / right, base.py:471-476
+    const int turn = act == ACT_LEFT ? 3 : (act == ACT_RIGHT ? 1 : 0);
+    e.r = r0;
+    e.r.x = (r0.x & 0xFF00FFFFu) | (static_cast<uint32_t>((dir + turn) & 3) << 16);
+    // the cell in front, agent.py:153-160
+    e.fxy = front_xy(r0.x);
+    const uint32_t fx = e.fxy & 0xFF, fy = e.fxy >> 8;
+    const bool on_cell = alive && act >= ACT_FORWARD && act <= ACT_TOGGLE && fx < static_cast<uint32_t>(p.W()) &&
+                         fy < static_cast<uint32_t>(p.H());
+    e.ci = fx * p.H() + fy;
+    e.w = w;
+    const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
+    const int ct = r0.y & 0xFF, cc = (r0.y >> 8) & 0xFF, cs = (r0.y >> 16) & 0xFF;
+    const bool blue = p.kind() == MG_KIND_REDBLUEDOORS && e.fxy == blue_xy;
+    // state of the world OBJECT: equals the cell except for the blue door re-closed by
+    // redbluedoors.py:185 without a grid.update
+    const int so = (blue && (flags & FLAG_STALE)) ? S_CLOSED : s;
+    const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA || (t == T_DOOR && so == S_OPEN);
+    const bool fwd = on_cell && act == ACT_FORWARD && can_overlap;                  // base.py:479-483
+    const bool drop = on_cell && act == ACT_DROP && ct != T_EMPTY && t == T_EMPTY;  // base.py:507-511
+    const bool pk = on_cell && act == ACT_PICKUP && (t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY;  // :497-504
+    const bool door = on_cell && act == ACT_TOGGLE && t == T_DOOR;  // Door.toggle, world_object.py:456-472
+    const bool unlock = door && so == S_LOCKED && ct == T_KEY && cc == c;
+    const bool flip = door && so != S_LOCKED;
+    const bool box = on_cell && act == ACT_TOGGLE && t == T_BOX;  // Box.toggle, no contents, world_object.py:653-659
+    e.nv = (pk || box) ? CELL_EMPTY
+           : drop      ? pack_cell(ct, cc, cs)
+                       : pack_cell(T_DOOR, c, (unlock || so != S_OPEN) ? S_OPEN : S_CLOSED);
+    e.bits = (alive ? EV_ALIVE : 0u) | (on_cell ? EV_ONCELL : 0u) | (fwd ? EV_FWD : 0u) | (drop ? EV_DROP : 0u) |
+             (pk ? EV_PK : 0u) | (unlock ? EV_UNLOCK : 0u) | (flip ? EV_FLIP : 0u) | (box ? EV_BOX : 0u) |
+             (blue ? EV_BLUE : 0u);
+    return e;
+}
+
+// does the action have to know whether an agent stands in front?  (forward without overlap, drop)
+__device__ __forceinline__ bool needs_occupancy(const KParams &p, const ActEval &e) {
+    return ((e.bits & EV_FWD) && !p.overlap()) || (e.bits & EV_DROP);
+}
+
+// `occupied`: some agent, terminated ones included, stands on the cell in front (base.py:485,512)
+__device__ __forceinline__ void finish_action(const KParams &p, ActEval &e, uint2 r0, bool occupied) {
+    const int t = e.w & 15;
+    const bool mv = (e.bits & EV_FWD) && !(occupied && !p.overlap());
+    const bool dr = (e.bits & EV_DROP) && !occupied;
+    if (mv) e.r.x = (e.r.x & 0xFFFF0000u) | e.fxy;  // base.py:489
+    // on_success / on_failure with the empty terminations dict of base.py:492,494: mode "any"
+    // terminates nobody here, mode "all" terminates this agent
+    const bool goal = mv && t == T_GOAL, lava = mv && t == T_LAVA;
+    if ((goal && !p.succ_any()) || (lava && !p.fail_any())) {
+        e.r.x |= 1u << 24;
+        e.bits |= EV_TERM;
+    }
+    if (goal) e.bits |= EV_GOAL;
+    if (e.bits & EV_PK)
+        e.r.y = (r0.y & 0xFF000000u) | static_cast<uint32_t>(t | (((e.w >> 8) & 127) << 8) | (((e.w >> 4) & 15) << 16));
+    if (dr) e.r.y = (r0.y & 0xFF000000u) | T_EMPTY;
+    if (dr || (e.bits & (EV_PK | EV_UNLOCK | EV_FLIP | EV_BOX))) e.bits |= EV_WRITE;
+}
+
 struct EnvView {
     uint8_t *rows;        // agent rows in LDS
     const uint16_t *fcv;  // front cells as of the start of the step (header block)
@@ -292,96 +385,111 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     reinterpret_cast<double *>(lds + p.o.R)[slot] =
         1.0 - static_cast<double>(step) * p.reward_slope;  // 1 - 0.9 * (step_count / max_steps), base.py:655-659
 
-    if (p.order == nullptr) {
-        const uint32_t key = order_key(p, env, h0.y, step);
-        for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
-        uint32_t word = 0;
-        for (int k = A - 1, f = 0; k > 0; --k, ++f) {
-            const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
-            const uint8_t t = ordb[k];
-            ordb[k] = ordb[j];
-            ordb[j] = t;
+    // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
+    const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
+    if ((fl0 >> 8) & 1) {
+        // the agents' actions touch each other: replay them one by one in the order of base.py:457-464
+        if (p.order == nullptr) {
+            const uint32_t key = order_key(p, env, h0.y, step);
+            for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
+            uint32_t word = 0;
+            for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                const uint8_t t = ordb[k];
+                ordb[k] = ordb[j];
+                ordb[j] = t;
+            }
         }
-    }
 
-    for (int k = 0; k < A; ++k) ev.rewm[k] = 0;  // base.py:454
+        for (int k = 0; k < A; ++k) ev.rewm[k] = 0;  // base.py:454
 
-    for (int n = 0; n < A; ++n) {  // base.py:464
-        const int i = ordb[n];
-        if (i >= A) continue;
-        uint8_t *a = ev.rows + 8 * i;
-        uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
-        const uint32_t w0 = ev.fcv[i];
-        if ((r.x >> 24) & 0xFF) continue;  // base.py:467
-        const int act = actb[i];
-        const int dir = (r.x >> 16) & 0xFF;
-        if (act == ACT_LEFT || act == ACT_RIGHT) {  // base.py:471-476
-            a[R_DIR] = static_cast<uint8_t>((dir + (act == ACT_LEFT ? 3 : 1)) & 3);
-            continue;
-        }
-        if (act >= ACT_DONE) continue;  // base.py:527-528
-        const uint32_t ci = front_index(p, r.x);
-        if (ci == FC_NONE) continue;  // front cell outside the grid: cannot happen inside border walls
-        const uint32_t fxy = front_xy(r.x);  // agent.py:153-160
-        const uint32_t w = cell_now(ev, ci, w0);
-        const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
-        const int ct = r.y & 0xFF, cc = (r.y >> 8) & 0xFF;
-        const bool blue = rbd && fxy == blue_xy;
-        // state of the world OBJECT: equals the cell except for the blue door re-closed by
-        // redbluedoors.py:185 without a grid.update
-        const int so = (blue && (ev.flags & FLAG_STALE)) ? S_CLOSED : s;
-        bool write = false, moved = false;
-        uint32_t nv = 0;
-        if (act == ACT_FORWARD) {  // base.py:479-494
-            const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
-                                     (t == T_DOOR && so == S_OPEN);
-            if (can_overlap && (p.overlap() || !agent_at(ev, fxy))) {
-                r.x = (r.x & 0xFFFF0000u) | fxy;
-                moved = true;
-                // on_success / on_failure with the empty terminations dict of base.py:492,494:
-                // mode "any" terminates nobody here, mode "all" terminates this agent
-                if (t == T_GOAL) {
-                    if (!p.succ_any()) r.x |= 1u << 24;
-                    if (p.joint())
-                        for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
-                    else
-                        ev.rewm[i] = 1;
-                }
-                if (t == T_LAVA && !p.fail_any()) r.x |= 1u << 24;
+        for (int n = 0; n < A; ++n) {  // base.py:464
+            const int i = ordb[n];
+            if (i >= A) continue;
+            uint8_t *a = ev.rows + 8 * i;
+            uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+            const uint32_t w0 = ev.fcv[i];
+            if ((r.x >> 24) & 0xFF) continue;  // base.py:467
+            const int act = actb[i];
+            const int dir = (r.x >> 16) & 0xFF;
+            if (act == ACT_LEFT || act == ACT_RIGHT) {  // base.py:471-476
+                a[R_DIR] = static_cast<uint8_t>((dir + (act == ACT_LEFT ? 3 : 1)) & 3);
+                continue;
             }
-        } else if (act == ACT_PICKUP) {  // base.py:497-504
-            if ((t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY) {
-                r.y = (r.y & 0xFF000000u) | static_cast<uint32_t>(t | (c << 8) | (s << 16));
-                moved = true;
-                write = true;
-                nv = CELL_EMPTY;
-            }
-        } else if (act == ACT_DROP) {  // base.py:507-516
-            if (ct != T_EMPTY && t == T_EMPTY && !agent_at(ev, fxy)) {
-                write = true;
-                nv = pack_cell(ct, cc, (r.y >> 16) & 0xFF);
-                r.y = (r.y & 0xFF000000u) | T_EMPTY;
-                moved = true;
-            }
-        } else {  // toggle, base.py:519-524
-            if (t == T_DOOR) {  // Door.toggle, world_object.py:456-472
-                if (so == S_LOCKED) {
-                    if (ct == T_KEY && cc == c) {
-                        write = true;
-                        nv = pack_cell(T_DOOR, c, S_OPEN);
+            if (act >= ACT_DONE) continue;  // base.py:527-528
+            const uint32_t ci = front_index(p, r.x);
+            if (ci == FC_NONE) continue;  // front cell outside the grid: cannot happen inside border walls
+            const uint32_t fxy = front_xy(r.x);  // agent.py:153-160
+            const uint32_t w = cell_now(ev, ci, w0);
+            const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
+            const int ct = r.y & 0xFF, cc = (r.y >> 8) & 0xFF;
+            const bool blue = rbd && fxy == blue_xy;
+            // state of the world OBJECT: equals the cell except for the blue door re-closed by
+            // redbluedoors.py:185 without a grid.update
+            const int so = (blue && (ev.flags & FLAG_STALE)) ? S_CLOSED : s;
+            bool write = false, moved = false;
+            uint32_t nv = 0;
+            if (act == ACT_FORWARD) {  // base.py:479-494
+                const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
+                                         (t == T_DOOR && so == S_OPEN);
+                if (can_overlap && (p.overlap() || !agent_at(ev, fxy))) {
+                    r.x = (r.x & 0xFFFF0000u) | fxy;
+                    moved = true;
+                    // on_success / on_failure with the empty terminations dict of base.py:492,494:
+                    // mode "any" terminates nobody here, mode "all" terminates this agent
+                    if (t == T_GOAL) {
+                        if (!p.succ_any()) r.x |= 1u << 24;
+                        if (p.joint())
+                            for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
+                        else
+                            ev.rewm[i] = 1;
                     }
-                } else {
-                    write = true;
-                    nv = pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN);
-                    if (blue) ev.flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+                    if (t == T_LAVA && !p.fail_any()) r.x |= 1u << 24;
                 }
-            } else if (t == T_BOX) {  // Box.toggle with no contents, world_object.py:653-659
-                write = true;
-                nv = CELL_EMPTY;
+            } else if (act == ACT_PICKUP) {  // base.py:497-504
+                if ((t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY) {
+                    r.y = (r.y & 0xFF000000u) | static_cast<uint32_t>(t | (c << 8) | (s << 16));
+                    moved = true;
+                    write = true;
+                    nv = CELL_EMPTY;
+                }
+            } else if (act == ACT_DROP) {  // base.py:507-516
+                if (ct != T_EMPTY && t == T_EMPTY && !agent_at(ev, fxy)) {
+                    write = true;
+                    nv = pack_cell(ct, cc, (r.y >> 16) & 0xFF);
+                    r.y = (r.y & 0xFF000000u) | T_EMPTY;
+                    moved = true;
+                }
+            } else {  // toggle, base.py:519-524
+                if (t == T_DOOR) {  // Door.toggle, world_object.py:456-472
+                    if (so == S_LOCKED) {
+                        if (ct == T_KEY && cc == c) {
+                            write = true;
+                            nv = pack_cell(T_DOOR, c, S_OPEN);
+                        }
+                    } else {
+                        write = true;
+                        nv = pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN);
+                        if (blue) ev.flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+                    }
+                } else if (t == T_BOX) {  // Box.toggle with no contents, world_object.py:653-659
+                    write = true;
+                    nv = CELL_EMPTY;
+                }
             }
+            if (moved) *reinterpret_cast<uint2 *>(a) = r;
+            if (write) ev.log[ev.nlog++] = ci | (nv << 16);
         }
-        if (moved) *reinterpret_cast<uint2 *>(a) = r;
-        if (write) ev.log[ev.nlog++] = ci | (nv << 16);
+    } else {
+        // independent actions: act_lanes() has applied them already
+        ev.nlog = (fl0 >> 16) & 0xFF;
+        if ((fl0 >> 24) & 1) ev.flags &= ~FLAG_STALE;
+        if (p.joint()) {  // base.py:558-559
+            bool any = false;
+            for (int k = 0; k < A; ++k) any |= ev.rewm[k] != 0;
+            if (any)
+                for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
+        }
     }
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
@@ -499,12 +607,11 @@ __device__ __forceinline__ void store_bytes(uint8_t *ptr, uint64_t w, int A) {
 // Same contract as act_env; `actw` / `ordw` hold the A action and order bytes (ordw is ignored when
 // the order is drawn on the device).
 __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env, uint64_t actw, uint64_t ordw) {
-    const int A = p.A(), W = p.W(), H = p.H();
+    const int A = p.A(), H = p.H();
     uint8_t *h = lds + p.o.hdr + slot * p.HS;
     uint8_t *rows = h + H_ROWS;
     const uint16_t *fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
     uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
-    int nlog = 0;
     const uint64_t ones = 0x0101010101010101ull >> (8 * (8 - A));  // byte k = 1 for k < A
 
     const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
@@ -517,86 +624,59 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     const double R = 1.0 - static_cast<double>(step) * p.reward_slope;  // 1 - 0.9 * (step_count / max_steps), base.py:655-659
     reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
 
-    if (p.order == nullptr) {  // see order_key()
-        const uint32_t key = order_key(p, env, h0.y, step);
-        ordw = 0x0706050403020100ull;
-        uint32_t word = 0;
-        for (int k = A - 1, f = 0; k > 0; --k, ++f) {
-            const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
-            const uint64_t d = byte_of(ordw, k) ^ byte_of(ordw, j);
-            ordw ^= (d << (8 * k)) ^ (d << (8 * j));
-        }
-    }
+    // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
+    const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
+    int nlog = (fl0 >> 16) & 0xFF;
+    uint64_t termw, rewmw;  // byte k: agent k terminated / reward multiplier
 
-    uint64_t termw = 0, rewmw = 0;  // byte k: agent k terminated / reward multiplier
-#pragma unroll
-    for (int k = 0; k < 8; ++k) termw |= static_cast<uint64_t>(rows[8 * min(k, A - 1) + R_TERM]) << (8 * k);
-    termw &= ones * 0xFF;
+    if ((fl0 >> 8) & 1) {
+        // the agents' actions touch each other: replay them one by one in the order of base.py:457-464
+        if (p.order == nullptr) {  // see order_key()
+            const uint32_t key = order_key(p, env, h0.y, step);
+            ordw = 0x0706050403020100ull;
+            uint32_t word = 0;
 #pragma unroll 1
-
-    for (int n = 0; n < A; ++n) {  // base.py:464
-        const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
-        uint8_t *a = rows + 8 * i;
-        const uint2 r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
-        const uint32_t w0 = fcv[i];
-        const int act = byte_of(actw, i);
-        const bool alive = (r0.x >> 24) == 0;  // base.py:467
-        const int dir = (r0.x >> 16) & 3;
-        uint2 r = r0;
-        // left / right, base.py:471-476
-        const int turn = act == ACT_LEFT ? 3 : (act == ACT_RIGHT ? 1 : 0);
-        r.x = (r.x & 0xFF00FFFFu) | (static_cast<uint32_t>((dir + turn) & 3) << 16);
-        // the cell in front, agent.py:153-160
-        const uint32_t fxy = front_xy(r0.x);
-        const uint32_t fx = fxy & 0xFF, fy = fxy >> 8;
-        const bool on_cell = alive && act >= ACT_FORWARD && act <= ACT_TOGGLE &&
-                             fx < static_cast<uint32_t>(W) && fy < static_cast<uint32_t>(H);
-        const uint32_t ci = fx * H + fy;
-        uint32_t w = w0;
+            for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                const uint64_t d = byte_of(ordw, k) ^ byte_of(ordw, j);
+                ordw ^= (d << (8 * k)) ^ (d << (8 * j));
+            }
+        }
+        termw = 0;
+        rewmw = 0;
+        nlog = 0;
 #pragma unroll 1
-        for (int j = 0; j < nlog; ++j) {  // cells already written during this step
-            const uint32_t e = log[j];
-            if ((e & 0xFFFF) == ci) w = e >> 16;
-        }
-        const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
-        const int ct = r0.y & 0xFF, cc = (r0.y >> 8) & 0xFF, cs = (r0.y >> 16) & 0xFF;
-        const bool blue = rbd && fxy == blue_xy;
-        // state of the world OBJECT: equals the cell except for the blue door re-closed by
-        // redbluedoors.py:185 without a grid.update
-        const int so = (blue && (flags & FLAG_STALE)) ? S_CLOSED : s;
-        const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA || (t == T_DOOR && so == S_OPEN);
-        const bool fwd = on_cell && act == ACT_FORWARD && can_overlap;            // base.py:479-483
-        const bool drop = on_cell && act == ACT_DROP && ct != T_EMPTY && t == T_EMPTY;  // base.py:507-511
-        bool occupied = false;  // base.py:485,512: every agent counts, terminated ones included
-        if ((fwd && !p.overlap()) || drop)
+        for (int k = 0; k < A; ++k) termw |= static_cast<uint64_t>(rows[8 * k + R_TERM]) << (8 * k);
 #pragma unroll 1
-            for (int k = 0; k < A; ++k) occupied |= *reinterpret_cast<const uint16_t *>(rows + 8 * k) == fxy;
-        const bool mv = fwd && !occupied;
-        const bool dr = drop && !occupied;
-        const bool pk = on_cell && act == ACT_PICKUP && (t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY;  // :497-504
-        const bool door = on_cell && act == ACT_TOGGLE && t == T_DOOR;  // Door.toggle, world_object.py:456-472
-        const bool unlock = door && so == S_LOCKED && ct == T_KEY && cc == c;
-        const bool flip = door && so != S_LOCKED;
-        const bool box = on_cell && act == ACT_TOGGLE && t == T_BOX;  // Box.toggle, no contents, world_object.py:653-659
-        if (mv) r.x = (r.x & 0xFFFF0000u) | fxy;  // base.py:489
-        // on_success / on_failure with the empty terminations dict of base.py:492,494: mode "any"
-        // terminates nobody here, mode "all" terminates this agent
-        const bool goal = mv && t == T_GOAL, lava = mv && t == T_LAVA;
-        if ((goal && !p.succ_any()) || (lava && !p.fail_any())) {
-            r.x |= 1u << 24;
-            termw |= 1ull << (8 * i);
+        for (int n = 0; n < A; ++n) {  // base.py:464
+            const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
+            uint8_t *a = rows + 8 * i;
+            const uint2 r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+            uint32_t w = fcv[i];
+            const uint32_t ci0 = front_index(p, r0.x);
+#pragma unroll 1
+            for (int j = 0; j < nlog; ++j) {  // cells already written during this step
+                const uint32_t e = log[j];
+                if ((e & 0xFFFF) == ci0) w = e >> 16;
+            }
+            ActEval ev = eval_action(p, r0, w, byte_of(actw, i), flags, blue_xy);
+            bool occupied = false;  // base.py:485,512: every agent counts, terminated ones included
+            if (needs_occupancy(p, ev))
+#pragma unroll 1
+                for (int k = 0; k < A; ++k) occupied |= *reinterpret_cast<const uint16_t *>(rows + 8 * k) == ev.fxy;
+            finish_action(p, ev, r0, occupied);
+            if (ev.bits & EV_TERM) termw |= 1ull << (8 * i);
+            if (ev.bits & EV_GOAL) rewmw = p.joint() ? ones : ((rewmw & ~(0xFFull << (8 * i))) | (1ull << (8 * i)));  // base.py:558-562
+            if ((ev.bits & EV_FLIP) && (ev.bits & EV_BLUE)) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+            if ((ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
+            if (ev.bits & EV_WRITE) log[nlog++] = ev.ci | (ev.nv << 16);
         }
-        if (goal) rewmw = p.joint() ? ones : ((rewmw & ~(0xFFull << (8 * i))) | (1ull << (8 * i)));  // base.py:558-562
-        if (pk) r.y = (r0.y & 0xFF000000u) | static_cast<uint32_t>(t | (c << 8) | (s << 16));
-        if (dr) r.y = (r0.y & 0xFF000000u) | T_EMPTY;
-        if (flip && blue) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
-        if (alive && (r.x != r0.x || r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = r;
-        if (pk || dr || unlock || flip || box) {
-            const uint32_t nv = (pk || box) ? CELL_EMPTY
-                                : dr        ? pack_cell(ct, cc, cs)
-                                            : pack_cell(T_DOOR, c, (unlock || so != S_OPEN) ? S_OPEN : S_CLOSED);
-            log[nlog++] = ci | (nv << 16);
-        }
+    } else {
+        // independent actions: act_lanes() has applied them already
+        termw = load_bytes(lds + p.o.oterm + slot * A, A);
+        rewmw = load_bytes(lds + p.o.rewm + slot * A, A);
+        if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559
+        if ((fl0 >> 24) & 1) flags &= ~FLAG_STALE;
     }
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
@@ -708,6 +788,75 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     }
 }
 
+// ---- act, one lane per agent -----------------------------------------------------------------------
+//
+// Agents of one environment rarely get in each other's way within a single step.  Every lane works
+// out its agent's action against the state at the start of the step and publishes what the others
+// need to know; a second look decides whether any agent of the environment could meet a different
+// world when the actions are taken one by one: a cell in front of it that someone else may write,
+// or - where it matters whether the cell in front is occupied - an agent about to walk into or out
+// of that cell.  Such environments are left untouched for the replay in act_env*(); for the others
+// the result is final here, whatever the order.  Runs on the NE environments from `s0`; the scratch
+// array lives in the image staging area, which is idle during the act phase.
+__device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int s0, int ns, int lane, int my_slot,
+                                          int my_agent) {
+    const int A = p.A();
+    const bool mine = lane < ns * A;
+    uint8_t *h = lds + p.o.hdr + (s0 + my_slot) * p.HS;
+    uint8_t *a = h + H_ROWS + 8 * my_agent;
+    uint2 *pair = reinterpret_cast<uint2 *>(lds + p.o.img);
+    uint2 r0 = make_uint2(0u, 0u);
+    ActEval ev;
+    ev.r = r0;
+    ev.fxy = ev.ci = ev.w = ev.nv = ev.bits = 0u;
+    if (mine) {
+        r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
+        const uint32_t w0 = reinterpret_cast<const uint16_t *>(h + p.HFC)[my_agent];
+        const uint2 hm = *reinterpret_cast<const uint2 *>(h + H_FLAGS);  // flags, door positions
+        ev = eval_action(p, r0, w0, lds[p.o.act + s0 * A + lane], hm.x & 0xFF, hm.y >> 16);
+    }
+    const bool need_occ = mine && needs_occupancy(p, ev);
+    bool occupied = false, clash = false;
+    // when nobody may write a cell and nobody asks where the others stand (the usual case in open
+    // rooms that allow overlap) there is nothing to compare
+    if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+    if (mine) pair[lane] = make_uint2((r0.x & 0xFFFFu) | (ev.fxy << 16), ev.bits);
+    wave_sync();
+    if (mine) {
+        const uint2 *q = pair + my_slot * A;
+#pragma unroll 2
+        for (int k = 0; k < A; ++k) {
+            const uint2 o = q[k];
+            const bool at_front = (o.x & 0xFFFFu) == ev.fxy, same_front = (o.x >> 16) == ev.fxy;
+            occupied |= at_front;  // base.py:485,512: every agent counts, terminated ones included
+            if (k != my_agent) {
+                clash |= (ev.bits & EV_ONCELL) && same_front && (o.y & EV_MAY_WRITE);
+                clash |= need_occ && (o.y & EV_FWD) && (at_front || same_front);
+            }
+        }
+    }
+    }
+    const uint64_t group = (A == 64 ? ~0ull : ((1ull << A) - 1ull)) << (my_slot * A);
+    const bool replay = (__ballot(clash) & group) != 0;
+    finish_action(p, ev, r0, occupied);
+    const bool final_here = mine && !replay;
+    const bool wr = final_here && (ev.bits & EV_WRITE);
+    const uint64_t writers = __ballot(wr) & group;
+    const uint64_t resync = __ballot(final_here && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE)) & group;
+    if (final_here) {
+        if ((ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
+        if (wr)
+            reinterpret_cast<uint32_t *>(lds + p.o.log)[(s0 + my_slot) * A + __popcll(writers & ((1ull << lane) - 1ull))] =
+                ev.ci | (ev.nv << 16);
+        lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>((r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u));
+        lds[p.o.rewm + s0 * A + lane] = (ev.bits & EV_GOAL) ? 1 : 0;  // base.py:558-562
+    }
+    if (mine && my_agent == 0)  // picked up by act_env*()
+        *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) =
+            (replay ? 0x100u : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) | (resync ? 1u << 24 : 0u);
+    wave_sync();
+}
+
 // Replace one environment's header in LDS and its grid in HBM by a start state from the pool
 // (MultiGridEnv.reset, multigrid/base.py:310-362, with the layout precomputed on the host).
 // Executed by the whole wavefront for one environment at a time.
@@ -729,10 +878,10 @@ __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int s
 
 // gen_obs_grid_encoding for one agent: multigrid/utils/obs.py:64-99 (gen_obs_grid :127-203,
 // get_view_exts :272-310, get_vis_mask :231-269), written for a grid that already carries
-// the agent overlay.  Image bytes go to `out` in [u][v][3] order.
+// the agent overlay.  The image comes back in registers, as the words of its [u][v][3] byte stream.
 template <int V, bool SEE>
 __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *row, const uint8_t *gbytes,
-                                              uint8_t *out) {
+                                              uint32_t (&px)[(3 * V * V + 3) / 4]) {
     constexpr int HALF = V / 2;
     const int W = p.W(), H = p.H();
     const int x = row[R_X], y = row[R_Y], dir = row[R_DIR];
@@ -817,13 +966,19 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
                 cell[u * V + v] = ((vis[v] >> u) & 1u) ? cell[u * V + v] : 0u;  // UNSEEN (0,0,0), obs.py:14,97
     }
 
+    // (type, colour, state) byte triples: type and colour already sit in the low nibbles of bytes 0
+    // and 1, the state nibble moves up by 12 bits
 #pragma unroll
-    for (int k = 0; k < V * V; ++k) {
-        const uint32_t w = cell[k];
-        out[3 * k + 0] = static_cast<uint8_t>(w & 15);
-        out[3 * k + 1] = static_cast<uint8_t>((w >> 8) & 127);
-        out[3 * k + 2] = static_cast<uint8_t>((w >> 4) & 15);
+    for (int k = 0; k < V * V; ++k) cell[k] = (cell[k] | (cell[k] << 12)) & 0x0F0F0Fu;
+    // four triples make three words of the byte stream
+#pragma unroll
+    for (int k = 0; k + 3 < V * V; k += 4) {
+        px[3 * (k / 4) + 0] = __builtin_amdgcn_perm(cell[k + 1], cell[k + 0], 0x04020100u);
+        px[3 * (k / 4) + 1] = __builtin_amdgcn_perm(cell[k + 2], cell[k + 1], 0x05040201u);
+        px[3 * (k / 4) + 2] = __builtin_amdgcn_perm(cell[k + 3], cell[k + 2], 0x06050402u);
     }
+    static_assert(V * V % 4 == 1, "odd view sizes leave one trailing cell");
+    px[3 * (V * V / 4)] = cell[V * V - 1];
 }
 
 #ifdef MGRID_EXPERIMENT
@@ -864,13 +1019,11 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     int *lsrc = reinterpret_cast<int *>(lds + p.o.src);
 
     MG_STAMP(0);
-    // up to 8 agents: each environment's action and order bytes ride in two registers of its act lane
+#ifdef MGRID_EXPERIMENT
+    unsigned long long tstart = 0;
+    MG_TICK(tstart);
+#endif
     constexpr bool small = SMALLA;  // A <= 8, chosen by the host
-    uint64_t actw = 0, ordw = 0;
-    if (MODE == MODE_STEP && small && lane < net) {
-        actw = load_bytes(p.actions + static_cast<size_t>(e0 + lane) * A, A);
-        if (p.order) ordw = load_bytes(p.order + static_cast<size_t>(e0 + lane) * A, A);
-    }
     // which environments take part (a masked reset skips some)
     bool active = lane < net;
     if (MODE == MODE_RESET && active && p.mask) active = p.mask[e0 + lane] != 0;
@@ -947,10 +1100,19 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     // environments that turn out to be reset are fetched again from the pool below.
     if (passes && MODE != MODE_RESET) issue(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == MODE_STEP && !small) {
-        for (int s = lane; s < nag; s += 64) {
-            lds[p.o.act + s] = p.actions[static_cast<size_t>(e0) * A + s];
-            if (p.order) lds[p.o.ord + s] = p.order[static_cast<size_t>(e0) * A + s];
+    if (MODE == MODE_STEP) {
+        const uint8_t *ga = p.actions + static_cast<size_t>(e0) * A, *go = p.order ? p.order + static_cast<size_t>(e0) * A : nullptr;
+        const bool words = ((reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(go)) & 3) == 0;
+        for (int s = 4 * lane; s < nag; s += 256) {
+            if (words && s + 4 <= nag) {
+                *reinterpret_cast<uint32_t *>(lds + p.o.act + s) = *reinterpret_cast<const uint32_t *>(ga + s);
+                if (go) *reinterpret_cast<uint32_t *>(lds + p.o.ord + s) = *reinterpret_cast<const uint32_t *>(go + s);
+            } else {
+                for (int b = s; b < min(s + 4, nag); ++b) {
+                    lds[p.o.act + b] = ga[b];
+                    if (go) lds[p.o.ord + b] = go[b];
+                }
+            }
         }
     }
     wave_sync();
@@ -985,14 +1147,42 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 
     MG_STAMP(1);
     // ---- act ---------------------------------------------------------------------------------------
+    const int my_slot = udiv(lane, p.magic_a);  // environment (within a sub-tile) of this lane's agent
+    const int my_agent = lane - my_slot * A;
+#ifdef MGRID_EXPERIMENT
+    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0;
+    MG_TICK(ta0);
+#endif
     if (MODE == MODE_STEP) {
+        if (A >= PARALLEL_ACT_MIN_AGENTS) {
+#pragma unroll 1
+            for (int s0 = 0; s0 < net; s0 += NE) act_lanes(p, lds, s0, min(NE, net - s0), lane, my_slot, my_agent);
+        } else if (lane < net) {
+            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = 0x100u;  // replay every environment in order
+        }
+        wave_sync();
+#ifdef MGRID_EXPERIMENT
+        MG_TICK(ta1);
+        const int n_replay = __popcll(__ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0));
+#endif
         if (lane < net) {
             if constexpr (small)
-                act_env_small(p, lds, lane, e0 + lane, actw, ordw);
+                act_env_small(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
+                              p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
             else
                 act_env(p, lds, lane, e0 + lane);
         }
         wave_sync();
+#ifdef MGRID_EXPERIMENT
+        MG_TICK(ta2);
+        if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
+            unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 20;
+            d[0] = ta0 - tstart;  // staging
+            d[1] = ta1 - ta0;     // act, lane per agent
+            d[2] = ta2 - ta1;     // act, lane per environment
+            d[4] = n_replay;      // environments whose agents' actions had to be replayed in order
+        }
+#endif
         MG_STAMP(2);
         if (p.autoreset() == MG_AUTORESET_SAME_STEP) {
             uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
@@ -1018,8 +1208,6 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     MG_STAMP(3);
     // ---- observe: NE environments at a time -------------------------------------------------------------
     if (passes) {
-        const int my_slot = udiv(lane, p.magic_a);  // environment (within the sub-tile) of this lane's agent
-        const int my_agent = lane - my_slot * A;
         if (MODE == MODE_RESET) issue(0);
         commit(0);
         wave_sync();
@@ -1104,19 +1292,15 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             wave_sync();
 
             if (s0 == 0) MG_STAMP(6);
-            const size_t out_base = (static_cast<size_t>(e0 + s0) * A) * IMG;  // byte offset of the sub-tile's images
-            // The LDS stream sits `shift` bytes into its buffer so that LDS and HBM agree modulo 16.
-            const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
+            constexpr int NPX = (IMG + 3) / 4;
+            uint32_t px[NPX];
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) px[k] = 0u;
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 1))
 #endif
             if (want_img && mine)
-                observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16),
-#ifdef MGRID_EXPERIMENT
-                                      lds + p.o.img + shift + (lane % (64 / (1 + ((p.dbg >> 8) & 3)))) * IMG);
-#else
-                                      lds + p.o.img + shift + lane * IMG);
-#endif
+                observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16), px);
             wave_sync();
             // the next sub-tile's grids may now replace this one's
 #ifdef MGRID_EXPERIMENT
@@ -1130,42 +1314,73 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #endif
 
             if (s0 == 0) MG_STAMP(7);
-            uint8_t *gdst = p.image + out_base - shift;
-            const int total = shift + np * IMG;
-            const int nchunk = (total + 15) / 16;
+            // Images leave through a small LDS buffer, STAGE_LANES agents at a time: their lanes lay the
+            // byte streams down back to back, then the whole wavefront stores the block as 16-byte pieces.
+            // The stream sits `shift` bytes into the buffer so that LDS and HBM agree modulo 16.
+            const size_t tile_base = (static_cast<size_t>(e0 + s0) * A) * IMG;  // byte offset of the sub-tile's images
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 2))
 #endif
-            if (want_img && all_active && shift == 0 && (total & 15) == 0) {
-                // whole, aligned stream: all LDS reads first, then all stores
-                constexpr int MAXIT = (64 * IMG + 1023) / 1024;
+            if (want_img && all_active && np % STAGE_LANES == 0 &&
+                ((reinterpret_cast<uintptr_t>(p.image) + tile_base) & 15) == 0) {
+                // whole blocks, 16-byte aligned in HBM (STAGE_LANES * IMG is a multiple of 16)
+                constexpr int CH = STAGE_LANES * IMG / 16;  // 16-byte pieces per block
+                constexpr int MAXIT = (CH + 63) / 64;
+                uint8_t *wdst = lds + p.o.img + (lane & (STAGE_LANES - 1)) * IMG;
                 const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.img);
-                uint4 *dst16 = reinterpret_cast<uint4 *>(gdst);
-                uint4 ob[MAXIT];
+                uint4 *dst16 = reinterpret_cast<uint4 *>(p.image + tile_base) + lane;
 #pragma unroll
-#ifdef MGRID_EXPERIMENT
-                for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, nchunk - 1) % (nchunk / (1 + ((p.dbg >> 8) & 3)))];
-#else
-                for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, nchunk - 1)];
-#endif
+                for (int r = 0; r < 64 / STAGE_LANES; ++r) {
+                    if (r * STAGE_LANES < np) {
+                        if (lane / STAGE_LANES == r) {
 #pragma unroll
-                for (int it = 0; it < MAXIT; ++it)
-                    if (it * 64 + lane < nchunk) dst16[it * 64 + lane] = ob[it];
-            } else if (want_img) {
-              for (int c = lane; c < nchunk; c += 64) {
-                const int b0 = 16 * c;
-                if (all_active && b0 >= shift && b0 + 16 <= total) {
-                    *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o.img + b0);
-                } else {
-                    for (int b = b0; b < b0 + 16; ++b) {
-                        if (b < shift || b >= total) continue;
-                        const int slot = ((b - shift) / IMG) / A;
-                        if ((sub_mask >> slot) & 1) gdst[b] = lds[p.o.img + b];
+                            for (int k = 0; k + 4 <= NPX; k += 4) __builtin_memcpy(wdst + 4 * k, &px[k], 16);
+#pragma unroll
+                            for (int k = NPX / 4 * 4; k < NPX; ++k) __builtin_memcpy(wdst + 4 * k, &px[k], min(4, IMG - 4 * k));
+                        }
+                        wave_sync();
+                        uint4 ob[MAXIT];  // all LDS reads first, then all stores
+#pragma unroll
+                        for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, CH - 1)];
+#pragma unroll
+                        for (int it = 0; it < MAXIT; ++it)
+                            if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it];
+                        wave_sync();
                     }
                 }
+            } else if (want_img) {
+#pragma unroll 1
+                for (int l0 = 0; l0 < np; l0 += STAGE_LANES) {
+                    const int nl = min(STAGE_LANES, np - l0);
+                    const size_t out_base = tile_base + static_cast<size_t>(l0) * IMG;  // byte offset of the block
+                    const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
+                    if (mine && lane >= l0 && lane < l0 + nl) {
+                        uint8_t *dst = lds + p.o.img + shift + (lane - l0) * IMG;
+#pragma unroll
+                        for (int k = 0; k + 4 <= NPX; k += 4) __builtin_memcpy(dst + 4 * k, &px[k], 16);
+#pragma unroll
+                        for (int k = NPX / 4 * 4; k < NPX; ++k) __builtin_memcpy(dst + 4 * k, &px[k], min(4, IMG - 4 * k));
+                    }
+                    wave_sync();
+                    uint8_t *gdst = p.image + out_base - shift;
+                    const int total = shift + nl * IMG;
+                    const int nchunk = (total + 15) / 16;
+#pragma unroll 1
+                    for (int c = lane; c < nchunk; c += 64) {
+                        const int b0 = 16 * c;
+                        if (all_active && b0 >= shift && b0 + 16 <= total) {
+                            *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o.img + b0);
+                        } else {
+                            for (int bb = b0; bb < b0 + 16; ++bb) {
+                                if (bb < shift || bb >= total) continue;
+                                const int slot = (l0 + (bb - shift) / IMG) / A;
+                                if ((sub_mask >> slot) & 1) gdst[bb] = lds[p.o.img + bb];
+                            }
+                        }
+                    }
+                    wave_sync();
+                }
             }
-            }
-            wave_sync();
             if (s0 == 0) MG_STAMP(8);
 #ifdef MGRID_EXPERIMENT
             MG_TICK(tk3);
@@ -1219,6 +1434,13 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             if ((active_mask >> udiv(i, per_h == 1 ? 0u : (0xFFFFFFFFu / per_h + 1u))) & 1) dh[i] = sh[i];
     }
     MG_STAMP(10);
+#ifdef MGRID_EXPERIMENT
+    {
+        unsigned long long tend = 0;
+        MG_TICK(tend);
+        if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 23] = tend - tstart;
+    }
+#endif
 }
 
 // ---- reference-layout <-> device-layout conversion (debug / parity path) -------------------------------
@@ -1435,8 +1657,8 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
         kp.o.hdr = take(et * kp.HS);
         kp.o.log = take(4 * et * c.num_agents);
-        kp.o.act = take(c.num_agents > 8 ? et * c.num_agents : 0);  // up to 8 agents: in registers
-        kp.o.ord = take(c.num_agents > 8 ? et * c.num_agents : 0);
+        kp.o.act = take(et * c.num_agents);
+        kp.o.ord = take(et * c.num_agents);
         kp.o.rewm = take(et * c.num_agents);
         kp.o.tout = take(et * c.num_agents);
         kp.o.oterm = take(et * c.num_agents);
@@ -1444,17 +1666,19 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         kp.o.R = take(8 * et);
         kp.o.src = take(4 * et);
         kp.o.grid = take(ne * (kp.GS + 16));  // 16 bytes between grids spread them over the LDS banks
-        kp.o.img = take(np * img + 32);
+        kp.o.img = take(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np));  // doubles as act_lanes() scratch
         return o;
     };
-    // Measured on MI355X: about 32 environments per wavefront is the sweet spot between act-phase
-    // lane use and LDS-limited occupancy.
+    // Measured on MI355X: with the in-order act phase (one lane per environment) about 32 environments
+    // per wavefront balance lane use against LDS-limited occupancy; with the lane-per-agent act phase
+    // 16 are enough and leave room for more wavefronts per CU.
     int ne = 64 / c.num_agents;
     const int want_waves = 2048;
     while (ne > 1 && (c.num_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
     while (ne > 1 && lds_for(ne, 1) > 40 * 1024) --ne;
     int g = 1;
-    while ((g + 1) * ne <= 32 && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
+    const int et_target = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? 16 : 32;
+    while ((g + 1) * ne <= et_target && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
     if (const char *ev = getenv("MGRID_TILE")) {  // tuning override: "NE,G"
@@ -1470,8 +1694,6 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     if (const char *ev = getenv("MGRID_DBG")) {
         kp.dbg = atoi(ev);
         if (kp.dbg & 32) h->lds_bytes = static_cast<size_t>(kp.o.grid);  // act phase alone
-        const int k = 1 + ((kp.dbg >> 8) & 3);  // wrong results on purpose: image staging shared by k lane groups
-        h->lds_bytes -= static_cast<size_t>(round_up((ne * c.num_agents * img) * (k - 1) / k, 16));
     }
 #endif
     if (h->lds_bytes > 64 * 1024) {
@@ -1526,8 +1748,8 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
         uint16_t *gd = reinterpret_cast<uint16_t *>(pg.data() + static_cast<size_t>(l) * kp.GS);
         for (int c = 0; c < cells; ++c) {
             const uint8_t *s = grids + (static_cast<size_t>(l) * cells + c) * 3;
-            if (s[0] > 15 || s[1] > 127 || s[2] > 15)
-                return fail(h, MG_EINVAL, "layout %d cell %d = (%d,%d,%d) exceeds type<16, color<128, state<16", l, c,
+            if (s[0] > 15 || s[1] > 15 || s[2] > 15)
+                return fail(h, MG_EINVAL, "layout %d cell %d = (%d,%d,%d) exceeds type<16, color<16, state<16", l, c,
                             s[0], s[1], s[2]);
             const uint32_t opaque = (s[0] == T_WALL) | ((s[0] == T_DOOR) & (s[2] != S_OPEN));
             gd[c] = static_cast<uint16_t>(s[0] | (s[2] << 4) | (s[1] << 8) | (opaque << 15));
@@ -1538,7 +1760,7 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
             if (ar[8 * k + R_X] >= kp.W() || ar[8 * k + R_Y] >= kp.H() || ar[8 * k + R_DIR] > 3)
                 return fail(h, MG_EINVAL, "layout %d agent %d at (%d,%d) dir %d is outside the grid", l, k,
                             ar[8 * k + R_X], ar[8 * k + R_Y], ar[8 * k + R_DIR]);
-            if (ar[8 * k + R_CT] > 15 || ar[8 * k + R_CC] > 127 || ar[8 * k + R_CS] > 15 || ar[8 * k + R_COLOR] > 127)
+            if (ar[8 * k + R_CT] > 15 || ar[8 * k + R_CC] > 15 || ar[8 * k + R_CS] > 15 || ar[8 * k + R_COLOR] > 15)
                 return fail(h, MG_EINVAL, "layout %d agent %d carries an out-of-range encoding", l, k);
         }
         memcpy(hd + H_ROWS, ar, static_cast<size_t>(A) * 8);

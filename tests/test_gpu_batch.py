@@ -23,6 +23,13 @@ CASES = {
     # more than 8 agents take the kernel's generic (LDS-array) act phase
     "big12": ("MultiGrid-Empty-16x16-v0", 12, dict(max_steps=40, allow_agent_overlap=False, success_termination_mode="all")),
     "big10": ("MultiGrid-LockedHallway-6Rooms-v0", 10, dict(max_steps=40)),
+    # crowded rooms: agents block each other and reach for the same objects within one step, which is
+    # what separates the lane-per-agent act phase from the in-order replay
+    "crowd8_empty": ("MultiGrid-Empty-5x5-v0", 8, dict(max_steps=30, allow_agent_overlap=False, success_termination_mode="all")),
+    "crowd8_rbd": ("MultiGrid-RedBlueDoors-6x6-v0", 8, dict(max_steps=40, allow_agent_overlap=False)),
+    "crowd8_bup": ("MultiGrid-BlockedUnlockPickup-v0", 8, dict(max_steps=60, joint_reward=True)),
+    "crowd6_lh": ("MultiGrid-LockedHallway-2Rooms-v0", 6, dict(max_steps=40)),
+    "crowd16_lh": ("MultiGrid-LockedHallway-4Rooms-v0", 16, dict(max_steps=40, allow_agent_overlap=False)),
 }
 
 

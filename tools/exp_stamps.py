@@ -33,6 +33,8 @@ def run(cfg, agents, e):
         prev = k
     if int(os.environ.get("MGRID_DBG", "0")) & 16:
         n = b[:, 19].sum()
+        print(f"   light ticks per wave: staging {b[:,20].mean():.0f}  act/agent lanes {b[:,21].mean():.0f}  act/env lanes {b[:,22].mean():.0f}  whole {b[:,23].mean():.0f} clk")
+        print(f"   replayed environments: {b[:,24].sum():.0f} of {e} in {(b[:,24] > 0).sum()} of {nt.value} tiles")
         print(f"   light ticks per pass: compute {b[:,16].sum()/n:.0f}  commit {b[:,17].sum()/n:.0f}  copy-out {b[:,18].sum()/n:.0f} clk ({n:.0f} passes)")
     env.close()
 
