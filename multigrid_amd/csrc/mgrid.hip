@@ -1326,7 +1326,23 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 // whole blocks, 16-byte aligned in HBM (STAGE_LANES * IMG is a multiple of 16)
                 constexpr int CH = STAGE_LANES * IMG / 16;  // 16-byte pieces per block
                 constexpr int MAXIT = (CH + 63) / 64;
-                uint8_t *wdst = lds + p.o.img + (lane & (STAGE_LANES - 1)) * IMG;
+                // An image is 4 M + 3 bytes, so four consecutive agents fill 4 M + 3 words exactly and agent j
+                // of such a quad starts j bytes before a word boundary.  Each lane shifts its stream by j bytes
+                // and owns the words (M + 1) j .. (M + 1) j + M - 1; the word after those straddles two agents
+                // and is put together with the first bytes of the next lane.  All LDS writes are then
+                // word-aligned with an odd word stride between lanes.
+                constexpr int M = IMG / 4;
+                const uint32_t px_first = px[0];
+                static_assert(IMG % 4 == 3 && NPX == M + 1, "3 V^2 with odd V is 3 mod 4");
+                const int j = lane & 3;
+#pragma unroll
+                for (int k = 0; k < M; ++k) px[k] = __builtin_amdgcn_alignbyte(px[k + 1], px[k], j);
+                {
+                    const uint32_t next0 = static_cast<uint32_t>(
+                        __builtin_amdgcn_update_dpp(0, static_cast<int>(px_first), 0xF9, 0xF, 0xF, false));  // quad_perm [1,2,3,3]
+                    px[M] = __builtin_amdgcn_alignbyte(next0 >> 8, (px[M] & 0xFFFFFFu) | (next0 << 24), j);
+                }
+                uint32_t *wdst = reinterpret_cast<uint32_t *>(lds + p.o.img) + ((lane & (STAGE_LANES - 1)) >> 2) * IMG + (M + 1) * j;
                 const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.img);
                 uint4 *dst16 = reinterpret_cast<uint4 *>(p.image + tile_base) + lane;
 #pragma unroll
@@ -1334,9 +1350,8 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                     if (r * STAGE_LANES < np) {
                         if (lane / STAGE_LANES == r) {
 #pragma unroll
-                            for (int k = 0; k + 4 <= NPX; k += 4) __builtin_memcpy(wdst + 4 * k, &px[k], 16);
-#pragma unroll
-                            for (int k = NPX / 4 * 4; k < NPX; ++k) __builtin_memcpy(wdst + 4 * k, &px[k], min(4, IMG - 4 * k));
+                            for (int k = 0; k < M; ++k) wdst[k] = px[k];
+                            if (j < 3) wdst[M] = px[M];
                         }
                         wave_sync();
                         uint4 ob[MAXIT];  // all LDS reads first, then all stores
