@@ -757,7 +757,8 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     store_bytes(lds + p.o.tout + slot * A, toutw, A);
     store_bytes(lds + p.o.rewm + slot * A, rewmw, A);
     const bool all_term = toutw == ones;
-    const int paid = static_cast<int>((rewmw * 0x0101010101010101ull) >> 56);
+    const int paid = static_cast<int>(__builtin_amdgcn_sad_u8(static_cast<uint32_t>(rewmw), 0u,
+                                      __builtin_amdgcn_sad_u8(static_cast<uint32_t>(rewmw >> 32), 0u, 0u)));  // sum of the bytes
     const bool over = trunc || all_term;
     if (over) flags |= FLAG_OVER;
     h[H_FLAGS] = static_cast<uint8_t>(flags);
@@ -1267,27 +1268,23 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 8))
 #endif
-            if (want_img && A > 1 && mine && !lds[p.o.oterm + (s0 + my_slot) * A + my_agent]) {
-                const uint2 r = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
-                const uint32_t xy = r.x & 0xFFFF;
-                bool top = true;
-                if constexpr (small) {  // all rows in flight at once
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) {
-                        const int kk = min(k, A - 1);
-                        const uint32_t rk = *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * kk);
-                        const bool hides = (rk & 0xFFFF) == xy && lds[p.o.oterm + (s0 + my_slot) * A + kk] == 0;
-                        top &= !(hides && kk > my_agent);
-                    }
-                } else {
-                    for (int k = my_agent + 1; k < A; ++k) {
-                        const uint32_t rk = *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * k);
-                        top &= ((rk & 0xFFFF) != xy) | (lds[p.o.oterm + (s0 + my_slot) * A + k] != 0);
-                    }
+            if (want_img && A > 1) {
+                // LDS writes of one wavefront land in program order, so drawing the agents index by index
+                // leaves the highest one on a shared cell without looking at the other agents at all
+                bool draw = false;
+                uint32_t ci = 0, val = 0;
+                if (mine && !lds[p.o.oterm + (s0 + my_slot) * A + my_agent]) {
+                    const uint2 r = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
+                    const unsigned x = r.x & 0xFF, y = (r.x >> 8) & 0xFF;
+                    draw = x < static_cast<unsigned>(p.W()) && y < static_cast<unsigned>(p.H());
+                    ci = x * p.H() + y;
+                    val = T_AGENT | (((r.x >> 16) & 0xFF) << 4) | ((r.y >> 24) << 8);
                 }
-                const unsigned x = xy & 0xFF, y = xy >> 8;
-                if (top && x < static_cast<unsigned>(p.W()) && y < static_cast<unsigned>(p.H()))
-                    my_grid[x * p.H() + y] = static_cast<uint16_t>(T_AGENT | (((r.x >> 16) & 0xFF) << 4) | ((r.y >> 24) << 8));
+#pragma unroll 1
+                for (int k = 0; k < A; ++k) {
+                    if (draw && my_agent == k) my_grid[ci] = static_cast<uint16_t>(val);
+                    asm volatile("" ::: "memory");  // one store per round, in this order
+                }
             }
             wave_sync();
 
