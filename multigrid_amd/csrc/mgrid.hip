@@ -1031,24 +1031,6 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     const uint64_t active_mask = __ballot(active);
     if (active_mask == 0) return;
 
-    // ---- header blocks (and, for a step, actions and order) -> LDS ------------------------------------
-    if (MODE != MODE_RESET) {
-        const uint4 *sh = reinterpret_cast<const uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
-        uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr);
-        const int nh = net * p.HS / 16;
-        for (int i0 = 0; i0 < nh; i0 += 64 * 4) {
-            uint4 buf[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) buf[c] = sh[min(i0 + c * 64 + lane, nh - 1)];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int i = i0 + c * 64 + lane;
-                if (i < nh) dh[i] = buf[c];
-            }
-        }
-    }
-    if (lane < ET) lsrc[lane] = -1;
-    wave_sync();
     const int per = p.GS / 16;
     const bool want_img = p.image != nullptr;
 #ifdef MGRID_EXPERIMENT
@@ -1097,24 +1079,50 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #undef MG_ISSUE1
 #undef MG_COMMIT1
 #undef MG_EACH
-    // The first sub-tile's loads go out before anything else so that they overlap the act phase;
-    // environments that turn out to be reset are fetched again from the pool below.
-    if (passes && MODE != MODE_RESET) issue(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (MODE == MODE_STEP) {
-        const uint8_t *ga = p.actions + static_cast<size_t>(e0) * A, *go = p.order ? p.order + static_cast<size_t>(e0) * A : nullptr;
-        const bool words = ((reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(go)) & 3) == 0;
-        for (int s = 4 * lane; s < nag; s += 256) {
-            if (words && s + 4 <= nag) {
-                *reinterpret_cast<uint32_t *>(lds + p.o.act + s) = *reinterpret_cast<const uint32_t *>(ga + s);
-                if (go) *reinterpret_cast<uint32_t *>(lds + p.o.ord + s) = *reinterpret_cast<const uint32_t *>(go + s);
-            } else {
-                for (int b = s; b < min(s + 4, nag); ++b) {
-                    lds[p.o.act + b] = ga[b];
-                    if (go) lds[p.o.ord + b] = go[b];
-                }
+    // ---- header blocks, actions, order and the first sub-tile's grids: every load goes out before the
+    // first of them is waited for; environments that turn out to be restarted get their grid from the
+    // pool later ----------------------------------------------------------------------------------------
+    {
+        const uint4 *sh = reinterpret_cast<const uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
+        uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr);
+        const int nh = MODE != MODE_RESET ? net * p.HS / 16 : 0;
+        uint4 hb0, hb1, hb2, hb3;
+        if (0 < nh) hb0 = sh[min(lane, nh - 1)];
+        if (64 < nh) hb1 = sh[min(64 + lane, nh - 1)];
+        if (128 < nh) hb2 = sh[min(128 + lane, nh - 1)];
+        if (192 < nh) hb3 = sh[min(192 + lane, nh - 1)];
+        const uint8_t *ga = nullptr, *go = nullptr;
+        bool words = false;
+        uint32_t aw = 0, ow = 0;
+        if (MODE == MODE_STEP) {
+            ga = p.actions + static_cast<size_t>(e0) * A;
+            go = p.order ? p.order + static_cast<size_t>(e0) * A : nullptr;
+            words = ((reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(go)) & 3) == 0;
+            if (words && 4 * lane + 4 <= nag) {
+                aw = *reinterpret_cast<const uint32_t *>(ga + 4 * lane);
+                if (go) ow = *reinterpret_cast<const uint32_t *>(go + 4 * lane);
             }
         }
+        if (passes && MODE != MODE_RESET) issue(0);
+        wave_sync();
+        if (lane < nh) dh[lane] = hb0;
+        if (64 + lane < nh) dh[64 + lane] = hb1;
+        if (128 + lane < nh) dh[128 + lane] = hb2;
+        if (192 + lane < nh) dh[192 + lane] = hb3;
+#pragma unroll 1
+        for (int i = 256 + lane; i < nh; i += 64) dh[i] = sh[i];
+        if (MODE == MODE_STEP) {
+            if (words && 4 * lane + 4 <= nag) {
+                *reinterpret_cast<uint32_t *>(lds + p.o.act + 4 * lane) = aw;
+                if (go) *reinterpret_cast<uint32_t *>(lds + p.o.ord + 4 * lane) = ow;
+            }
+#pragma unroll 1
+            for (int b = words ? min(nag & ~3, 256) + lane : lane; b < nag; b += 64) {  // what the words left over
+                lds[p.o.act + b] = ga[b];
+                if (go) lds[p.o.ord + b] = go[b];
+            }
+        }
+        if (lane < ET) lsrc[lane] = -1;
     }
     wave_sync();
 
