@@ -82,7 +82,7 @@ struct LdsMap {
 struct KParams {
     // configuration, packed so that it occupies few scalar registers
     uint32_t geo;   // W | H << 8 | A << 16 | NE << 24
-    uint32_t bits;  // kind (2) | overlap | joint | succ_any | fail_any | autoreset (2) | num_rooms (4) | G (8)
+    uint32_t bits;  // kind (2) | overlap | joint | succ_any | fail_any | autoreset (2) | num_rooms (4) | G (8) | walled
     __host__ __device__ int W() const { return geo & 0xFF; }
     __host__ __device__ int H() const { return (geo >> 8) & 0xFF; }
     __host__ __device__ int A() const { return (geo >> 16) & 0xFF; }
@@ -95,6 +95,7 @@ struct KParams {
     __host__ __device__ int autoreset() const { return (bits >> 6) & 3; }
     __host__ __device__ int num_rooms() const { return (bits >> 8) & 15; }
     __host__ __device__ int G() const { return (bits >> 12) & 0xFF; }
+    __host__ __device__ bool walled() const { return (bits >> 20) & 1; }  // every grid is ringed by (2,5,0) walls
     int max_steps;
     int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
     uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
@@ -880,7 +881,7 @@ __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int s
 // gen_obs_grid_encoding for one agent: multigrid/utils/obs.py:64-99 (gen_obs_grid :127-203,
 // get_view_exts :272-310, get_vis_mask :231-269), written for a grid that already carries
 // the agent overlay.  The image comes back in registers, as the words of its [u][v][3] byte stream.
-template <int V, bool SEE>
+template <int V, bool SEE, bool WALLED>
 __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *row, const uint8_t *gbytes,
                                               uint32_t (&px)[(3 * V * V + 3) / 4]) {
     constexpr int HALF = V / 2;
@@ -898,23 +899,24 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
     const int step_f = 2 * (fx * H + fy);
     const int base = 2 * (x * H + y);
 
-    // Per-u and per-v: is the world coordinate inside the grid, and the (clamped, always valid)
-    // byte offset contribution.
+    // Per-u and per-v: is the world coordinate inside the grid, and the byte offset contribution of
+    // the coordinate clamped into the grid.  A view cell outside the grid reads as a wall
+    // (obs.py:193-196); where every grid is ringed by exactly such walls the clamped read already
+    // returns one and no per-cell correction is needed.
     int off_u[V], off_v[V];
     uint32_t in_u = 0, in_v = 0;
+    const int stride_r = r_on_x ? 2 * H : 2, stride_f = r_on_x ? 2 : 2 * H;
 #pragma unroll
     for (int u = 0; u < V; ++u) {
         const int c = cr + (u - HALF) * sr;
-        const bool in = static_cast<unsigned>(c) < static_cast<unsigned>(lr);
-        in_u |= (in ? 1u : 0u) << u;
-        off_u[u] = in ? (u - HALF) * step_u : 0;
+        in_u |= (static_cast<unsigned>(c) < static_cast<unsigned>(lr) ? 1u : 0u) << u;
+        off_u[u] = (min(max(c, 0), lr - 1) - cr) * stride_r;
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int c = cf + (V - 1 - v) * sf;
-        const bool in = static_cast<unsigned>(c) < static_cast<unsigned>(lf);
-        in_v |= (in ? 1u : 0u) << v;
-        off_v[v] = base + (in ? (V - 1 - v) * step_f : 0);
+        in_v |= (static_cast<unsigned>(c) < static_cast<unsigned>(lf) ? 1u : 0u) << v;
+        off_v[v] = base + (min(max(c, 0), lf - 1) - cf) * stride_f;
     }
 
     uint32_t cell[V * V];
@@ -923,12 +925,21 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
     for (int v = 0; v < V; ++v) opq[v] = 0;
 #pragma unroll
     for (int u = 0; u < V; ++u) {
-        const uint32_t row_in = ((in_u >> u) & 1u) ? in_v : 0u;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             uint32_t w = *reinterpret_cast<const uint16_t *>(gbytes + off_v[v] + off_u[u]);
-            w = ((row_in >> v) & 1u) ? w : CELL_WALL;  // out of bounds -> wall, obs.py:193-196
+            // the load zero-extends; from here on the cell is a 32-bit value (keeps the compiler from
+            // re-deriving a 16-bit one and widening it again at every use)
+            asm("" : "+v"(w));
             cell[u * V + v] = w;
+        }
+    }
+    if (!WALLED) {
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            const uint32_t row_in = ((in_u >> u) & 1u) ? in_v : 0u;
+#pragma unroll
+            for (int v = 0; v < V; ++v) cell[u * V + v] = ((row_in >> v) & 1u) ? cell[u * V + v] : CELL_WALL;
         }
     }
     // the agent's own cell shows what it carries, obs.py:201
@@ -960,17 +971,20 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
             vis[v] = B;
             cur = (EA | (EA << 1) | EB | (EB >> 1)) & FULL;  // cells lit in the row above
         }
+        // (type, colour, state) byte triples: type and colour already sit in the low nibbles of bytes
+        // 0 and 1, the state nibble moves up by 12 bits; cells out of sight become UNSEEN (0,0,0),
+        // obs.py:14,97, through the same mask that clears the unused nibbles
 #pragma unroll
         for (int u = 0; u < V; ++u)
 #pragma unroll
-            for (int v = 0; v < V; ++v)
-                cell[u * V + v] = ((vis[v] >> u) & 1u) ? cell[u * V + v] : 0u;  // UNSEEN (0,0,0), obs.py:14,97
-    }
-
-    // (type, colour, state) byte triples: type and colour already sit in the low nibbles of bytes 0
-    // and 1, the state nibble moves up by 12 bits
+            for (int v = 0; v < V; ++v) {
+                const uint32_t keep = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(vis[v]), u, 1)) & 0x0F0F0Fu;
+                cell[u * V + v] = (cell[u * V + v] | (cell[u * V + v] << 12)) & keep;
+            }
+    } else {
 #pragma unroll
-    for (int k = 0; k < V * V; ++k) cell[k] = (cell[k] | (cell[k] << 12)) & 0x0F0F0Fu;
+        for (int k = 0; k < V * V; ++k) cell[k] = (cell[k] | (cell[k] << 12)) & 0x0F0F0Fu;
+    }
     // four triples make three words of the byte stream
 #pragma unroll
     for (int k = 0; k + 3 < V * V; k += 4) {
@@ -1007,7 +1021,7 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
 // the whole launch; grids are brought in NE environments ("sub-tile", NE * A <= 64 agent lanes)
 // at a time for the observation passes.
 
-template <int V, bool SEE, int MODE, bool SMALLA>
+template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED>
 __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int IMG = 3 * V * V;  // bytes per agent image
@@ -1227,11 +1241,6 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             const bool all_active = sub_mask == ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
             const bool has_next = s0 + NE < net;
 #ifdef MGRID_EXPERIMENT
-            if (!(p.dbg & 4))
-#endif
-            if (has_next) issue(s0 + NE);
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef MGRID_EXPERIMENT
             unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
             MG_TICK(tk0);
 #endif
@@ -1305,16 +1314,17 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             if (!(p.dbg & 1))
 #endif
             if (want_img && mine)
-                observe_agent<V, SEE>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16), px);
+                observe_agent<V, SEE, WALLED>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16), px);
             wave_sync();
-            // the next sub-tile's grids may now replace this one's
+            // The next sub-tile's grids set out now, travel while this sub-tile's images are stored and
+            // replace this sub-tile's grids in LDS at the end of the pass; they occupy registers only
+            // while the observation's own are free.
 #ifdef MGRID_EXPERIMENT
             MG_TICK(tk1);
-            if (!(p.dbg & 4))
 #endif
-            if (has_next) commit(s0 + NE);
+            if (has_next) issue(s0 + NE);
+            __builtin_amdgcn_sched_barrier(0);
 #ifdef MGRID_EXPERIMENT
-            if (p.dbg_buf && (p.dbg & 16)) { __builtin_amdgcn_s_waitcnt(0xC07F); }
             MG_TICK(tk2);
 #endif
 
@@ -1400,6 +1410,10 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                     }
                     wave_sync();
                 }
+            }
+            if (has_next) {
+                commit(s0 + NE);
+                wave_sync();
             }
             if (s0 == 0) MG_STAMP(8);
 #ifdef MGRID_EXPERIMENT
@@ -1558,6 +1572,7 @@ struct MgEnv {
     int64_t *stats = nullptr;
     int num_layouts = 0;
     bool reset_done = false;
+    bool pool_walled = false;
     uint32_t step_serial = 0;
     uint32_t reset_serial = 0;
     int64_t launches = 0;
@@ -1587,18 +1602,26 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int V, int MODE>
-void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
+template <int V, int MODE, bool WALLED>
+void launch_vmw(const MgEnv *h, const KParams &kp, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
     const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
     if (see && small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED>), grid, block, h->lds_bytes, s, kp);
     else if (see)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED>), grid, block, h->lds_bytes, s, kp);
     else if (small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED>), grid, block, h->lds_bytes, s, kp);
     else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED>), grid, block, h->lds_bytes, s, kp);
+}
+
+template <int V, int MODE>
+void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
+    if (kp.walled())
+        launch_vmw<V, MODE, true>(h, kp, s);
+    else
+        launch_vmw<V, MODE, false>(h, kp, s);
 }
 
 template <int MODE>
@@ -1763,6 +1786,7 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
     const KParams &kp = h->kp;
     const int cells = kp.W() * kp.H(), A = kp.A();
     std::vector<uint8_t> ph(static_cast<size_t>(n) * kp.HS, 0), pg(static_cast<size_t>(n) * kp.GS, 0);
+    bool walled = true;  // every layout ringed by walls that encode like "outside the grid" (obs.py:13)
     for (int l = 0; l < n; ++l) {
         uint8_t *hd = ph.data() + static_cast<size_t>(l) * kp.HS;
         uint16_t *gd = reinterpret_cast<uint16_t *>(pg.data() + static_cast<size_t>(l) * kp.GS);
@@ -1774,6 +1798,9 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
             const uint32_t opaque = (s[0] == T_WALL) | ((s[0] == T_DOOR) & (s[2] != S_OPEN));
             gd[c] = static_cast<uint16_t>(s[0] | (s[2] << 4) | (s[1] << 8) | (opaque << 15));
         }
+        for (int x = 0; x < kp.W(); ++x)
+            for (int y = 0; y < kp.H(); ++y)
+                if ((x == 0 || y == 0 || x == kp.W() - 1 || y == kp.H() - 1) && gd[x * kp.H() + y] != CELL_WALL) walled = false;
         if (meta) memcpy(hd + H_META, meta + static_cast<size_t>(l) * 4, 4);
         const uint8_t *ar = agents + static_cast<size_t>(l) * A * 8;
         for (int k = 0; k < A; ++k) {
@@ -1811,6 +1838,8 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
     h->kp.pool_hdr = h->pool_hdr;
     h->kp.pool_grid = h->pool_grid;
     h->kp.num_layouts = n;
+    h->pool_walled = walled;
+    if (!walled) h->kp.bits &= ~(1u << 20);
     return MG_OK;
 }
 
@@ -1827,6 +1856,8 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
     if (rc != MG_OK) return rc;
     h->reset_serial++;
     h->reset_done = true;
+    // after a reset of every environment all grids come from the pool
+    if (!mask_dev && h->pool_walled) h->kp.bits |= 1u << 20;
     return MG_OK;
 }
 
@@ -1883,6 +1914,7 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
                        0, static_cast<hipStream_t>(stream), h->kp);
     MG_HIP(h, hipGetLastError());
     h->reset_done = true;
+    if (grid_dev) h->kp.bits &= ~(1u << 20);  // grids of unknown shape: no assumption about their border
     return MG_OK;
 }
 
