@@ -882,11 +882,11 @@ __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int s
 // get_view_exts :272-310, get_vis_mask :231-269), written for a grid that already carries
 // the agent overlay.  The image comes back in registers, as the words of its [u][v][3] byte stream.
 template <int V, bool SEE, bool WALLED>
-__device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *row, const uint8_t *gbytes,
+__device__ __forceinline__ void observe_agent(const KParams &p, uint2 row, const uint8_t *gbytes,
                                               uint32_t (&px)[(3 * V * V + 3) / 4]) {
     constexpr int HALF = V / 2;
     const int W = p.W(), H = p.H();
-    const int x = row[R_X], y = row[R_Y], dir = row[R_DIR];
+    const int x = row.x & 0xFF, y = (row.x >> 8) & 0xFF, dir = (row.x >> 16) & 3;  // x y dir term | ct cc cs color
     // forward f and right r unit vectors; view cell (u, v) sits (u - HALF) to the right of and
     // (V - 1 - v) ahead of the agent, which is the rotation table of obs.py:174-190
     const int fx = dir_dx(dir), fy = dir_dy(dir);
@@ -943,7 +943,7 @@ __device__ __forceinline__ void observe_agent(const KParams &p, const uint8_t *r
         }
     }
     // the agent's own cell shows what it carries, obs.py:201
-    cell[HALF * V + (V - 1)] = pack_cell(row[R_CT], row[R_CC], row[R_CS]);
+    cell[HALF * V + (V - 1)] = pack_cell(row.y & 0xFF, (row.y >> 8) & 0xFF, (row.y >> 16) & 0xFF);
 
     if (!SEE) {
 #pragma unroll
@@ -1261,10 +1261,17 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 }
                 wave_sync();
             }
+            // this lane's agent as the act phase left it, read once for the rest of the pass
+            uint2 my_row = make_uint2(0u, 0u);
+            bool my_gone = true;  // terminated as far as gen_obs is concerned
+            if (mine) {
+                my_row = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
+                my_gone = lds[p.o.oterm + (s0 + my_slot) * A + my_agent] != 0;
+            }
             // front cells for the NEXT launch, taken before agents are drawn into the grid
             if (MODE != MODE_OBS) {
                 if (mine) {
-                    const uint32_t ci = front_index(p, *reinterpret_cast<const uint32_t *>(my_hdr + H_ROWS + 8 * my_agent));
+                    const uint32_t ci = front_index(p, my_row.x);
                     reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HS + p.HFC)[my_agent] =
                         ci == FC_NONE ? static_cast<uint16_t>(0) : my_grid[ci];
                 }
@@ -1290,8 +1297,8 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 // leaves the highest one on a shared cell without looking at the other agents at all
                 bool draw = false;
                 uint32_t ci = 0, val = 0;
-                if (mine && !lds[p.o.oterm + (s0 + my_slot) * A + my_agent]) {
-                    const uint2 r = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
+                if (mine && !my_gone) {
+                    const uint2 r = my_row;
                     const unsigned x = r.x & 0xFF, y = (r.x >> 8) & 0xFF;
                     draw = x < static_cast<unsigned>(p.W()) && y < static_cast<unsigned>(p.H());
                     ci = x * p.H() + y;
@@ -1314,7 +1321,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             if (!(p.dbg & 1))
 #endif
             if (want_img && mine)
-                observe_agent<V, SEE, WALLED>(p, my_hdr + H_ROWS + 8 * my_agent, lds + p.o.grid + my_slot * (p.GS + 16), px);
+                observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + my_slot * (p.GS + 16), px);
             wave_sync();
             // The next sub-tile's grids set out now, travel while this sub-tile's images are stored and
             // replace this sub-tile's grids in LDS at the end of the pass; they occupy registers only
