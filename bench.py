@@ -37,12 +37,14 @@ CONFIGS = {
 }
 
 
-def algorithmic_bytes_per_env_step(spec) -> int:
+def algorithmic_bytes_per_env_step(spec, one_hot=False) -> int:
     """Bytes one environment step has to move with uint8 fields, one step per launch:
     actions + order in, image + direction + reward + terminated + truncated out (156 per agent),
-    agent rows and environment scalars in and out, the whole grid in, changed cells out."""
-    a, w, h = spec["num_agents"], spec["width"], spec["height"]
-    return 156 * a + 2 * (8 * a + 8) + 3 * w * h + 3 * a
+    agent rows and environment scalars in and out, the whole grid in, changed cells out.
+    With one-hot observations the 3-byte cells of the image leave as 24 bytes each."""
+    a, w, h, v = spec["num_agents"], spec["width"], spec["height"], spec["view_size"]
+    img = v * v * (24 if one_hot else 3)
+    return (9 + img) * a + 2 * (8 * a + 8) + 3 * w * h + 3 * a
 
 
 def measured_traffic(cfg_id, num_envs):
@@ -61,7 +63,7 @@ def measured_traffic(cfg_id, num_envs):
     return best
 
 
-def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False):
+def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one_hot=False, **override):
     import numpy as np
     import torch
 
@@ -69,11 +71,11 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False):
     from multigrid_amd.batched import BatchedMultiGrid
 
     name, agents, _, kw = CONFIGS[cfg_id]
-    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(kw, **override))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
     env = BatchedMultiGrid(spec, num_envs, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
-                           env_id_offset=rank * num_envs, seed=1234)
+                           env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
     grids, ags, metas, _ = layouts.make_pool(gen, args.layouts, seed0=0)
     env.upload_layouts(grids, ags, metas)
     env.reset()
@@ -246,6 +248,18 @@ def main():
             extra.append({"baseline_config": cid, "workload": f"{n2}, {a2} agents, {e2} envs",
                           "value": e2 * a2 * 400 / x["wall"], "launch_us": ls * 1e6,
                           "roofline_frac": e2 * b2 / ls / 1e9 / HBM_PEAK_GBS})
+        # configs[4] again with agents blocking each other, and with one-hot observations
+        # (OneHotObsWrapper, multigrid/wrappers.py:60-146) written by the step launch instead of the compact image
+        n5, a5, e5, _ = CONFIGS[5]
+        for label, kw5, oh in (("allow_agent_overlap=False", dict(allow_agent_overlap=False), False),
+                               ("one-hot observations (V,V,24)", {}, True)):
+            x = gpu_leg(args, 5, e5, 0, 1, 200, 30, one_hot=oh, **kw5)
+            ls = x["gpu_s"] / 200
+            b5 = algorithmic_bytes_per_env_step(x["spec"], one_hot=oh)
+            extra.append({"baseline_config": 5, "workload": f"{n5}, {a5} agents, {e5} envs, {label}",
+                          "value": e5 * a5 * 200 / x["wall"], "launch_us": ls * 1e6,
+                          "algorithmic_bytes_per_env_step": b5,
+                          "roofline_frac": e5 * b5 / ls / 1e9 / HBM_PEAK_GBS})
         line["other_configs"] = extra
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_leg(args.config)

@@ -20,6 +20,7 @@
  *   meta     uint8 [E][4]        RedBlueDoors: red_x red_y blue_x blue_y (multigrid/envs/
  *                                redbluedoors.py:161-168); zeros for the other kinds
  *   image    uint8 [E][A][V][V][3]  obs["image"] of multigrid/base.py:430-436 (int64 there)
+ *   onehot   uint8 [E][A][V][V][24] the same image one-hot encoded, multigrid/wrappers.py:114-146
  * Cell fields are limited to type < 16, state < 16, color < 128 (the reference uses 11 / 7 / 6).
  */
 #ifndef MGRID_H
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 
 /* error codes */
 #define MG_OK 0
@@ -80,6 +81,9 @@ typedef struct MgOut {
     float *reward_dev;       /* [E][A]                                   base.py:454,560-562 */
     uint8_t *terminated_dev; /* [E][A]                                   base.py:400 + hooks */
     uint8_t *truncated_dev;  /* [E][A]                                   base.py:401-402 */
+    uint8_t *onehot_dev;     /* [E][A][V][V][24] the image as OneHotObsWrapper.observation returns
+                                it (multigrid/wrappers.py:105-146: 11 type, 6 colour and 7 state
+                                planes, wrappers.py:95), written by the same launch; 8-byte aligned */
 } MgOut;
 
 typedef struct MgEnv *MgHandle;
@@ -113,6 +117,15 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
  * uniform random permutation per environment and step on the device. */
 int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out,
             void *stream);
+
+/* `num_steps` consecutive mg_step calls queued by one call (a rollout whose actions are known up
+ * front, e.g. the random-action loop of multigrid/scripts/train_ppo_cleanrl.py:517-529 with the policy
+ * replaced by a table).  Every array gains a leading [num_steps] dimension: actions_dev
+ * uint8[T][E][A], order_dev uint8[T][E][A] or NULL, and each non-NULL pointer of `out`
+ * ([T][E][A][V][V][3] images, [T][E][A][V][V][24] one-hot images, [T][E][A] scalars); step t reads slice t and writes slice t.  Stops at
+ * the first step that fails and returns its code; steps before it have been queued. */
+int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const uint8_t *order_dev,
+              const MgOut *out, void *stream);
 
 /* Replaces MultiGridEnv.gen_obs (multigrid/base.py:410-438): image and direction of the current
  * state of every environment. */

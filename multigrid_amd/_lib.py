@@ -19,9 +19,11 @@ MG_OK = 0
 KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
+ABI_VERSION = 2
+ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts",
-           "mg_reset", "mg_step", "mg_gen_obs", "mg_get_state", "mg_set_state", "mg_stats")
+           "mg_reset", "mg_step", "mg_step_n", "mg_gen_obs", "mg_get_state", "mg_set_state", "mg_stats")
 
 
 class MgConfig(ctypes.Structure):
@@ -33,7 +35,7 @@ class MgConfig(ctypes.Structure):
 
 class MgOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev")]
+        "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev", "onehot_dev")]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -71,6 +73,7 @@ def lib() -> ctypes.CDLL:
         L.mg_upload_layouts.argtypes = [vp, vp, vp, vp, i32]
         L.mg_reset.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
+        L.mg_step_n.argtypes = [vp, i32, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_gen_obs.argtypes = [vp, ctypes.POINTER(MgOut), vp]
         L.mg_get_state.argtypes = [vp] * 7
         L.mg_set_state.argtypes = [vp] * 7

@@ -24,6 +24,7 @@ class StepOutput:
     reward: torch.Tensor      # float32 [E, A]
     terminated: torch.Tensor  # uint8 [E, A]
     truncated: torch.Tensor   # uint8 [E, A]
+    onehot: Optional[torch.Tensor] = None  # uint8 [E, A, V, V, 24], multigrid/wrappers.py:114-146
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -34,7 +35,10 @@ class BatchedMultiGrid:
     """``spec`` is a dict with the keys of ``MgConfig`` up to ``num_rooms`` (see include/mgrid.h)."""
 
     def __init__(self, spec: dict, num_envs: int, device: int | str | torch.device = 0,
-                 autoreset: int = _lib.AUTORESET_NONE, env_id_offset: int = 0, seed: int = 0):
+                 autoreset: int = _lib.AUTORESET_NONE, env_id_offset: int = 0, seed: int = 0,
+                 one_hot: bool = False, compact_image: bool = True):
+        """``one_hot``: also return the image as ``OneHotObsWrapper`` encodes it (multigrid/wrappers.py:60-146),
+        written by the same launch; ``compact_image=False`` then skips the ``(V, V, 3)`` image."""
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedMultiGrid needs a ROCm GPU (no CPU fallback)")
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
@@ -55,19 +59,20 @@ class BatchedMultiGrid:
         check(_lib.lib().mg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         e, a, v = self.E, self.A, self.V
         self.out = StepOutput(
-            image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev),
+            image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev) if compact_image or not one_hot else None,
             direction=torch.zeros((e, a), dtype=torch.uint8, device=dev),
             reward=torch.zeros((e, a), dtype=torch.float32, device=dev),
             terminated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
-            truncated=torch.zeros((e, a), dtype=torch.uint8, device=dev))
+            truncated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
+            onehot=torch.zeros((e, a, v, v, _lib.ONE_HOT_DIM), dtype=torch.uint8, device=dev) if one_hot else None)
         self._mgout = self._make_out(self.out)
         self.num_layouts = 0
 
     # -- plumbing -----------------------------------------------------------------
     @staticmethod
     def _make_out(o: StepOutput) -> MgOut:
-        return MgOut(o.image.data_ptr(), o.direction.data_ptr(), o.reward.data_ptr(),
-                     o.terminated.data_ptr(), o.truncated.data_ptr())
+        p = lambda t: None if t is None else t.data_ptr()
+        return MgOut(p(o.image), p(o.direction), p(o.reward), p(o.terminated), p(o.truncated), p(o.onehot))
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -126,6 +131,29 @@ class BatchedMultiGrid:
         mo = self._mgout if out is None else self._make_out(out)
         check(_lib.lib().mg_step(self._h, _ptr(act), _ptr(od), ctypes.byref(mo), self._stream()), self._h)
         return o
+
+    def step_n(self, actions, order=None, out: Optional[StepOutput] = None, one_hot: bool = False) -> StepOutput:
+        """T consecutive ``step`` calls queued by one library call; ``actions`` is ``[T, E, A]`` and every
+        tensor of the returned ``StepOutput`` has a leading ``T`` dimension."""
+        t_steps = int(torch.as_tensor(actions).shape[0])
+        act = self._dev_u8(actions, (t_steps, self.E, self.A))
+        od = None if order is None else self._dev_u8(order, (t_steps, self.E, self.A))
+        if out is None:
+            e, a, v, dev = self.E, self.A, self.V, self.device
+            out = StepOutput(
+                image=torch.empty((t_steps, e, a, v, v, 3), dtype=torch.uint8, device=dev),
+                direction=torch.empty((t_steps, e, a), dtype=torch.uint8, device=dev),
+                reward=torch.empty((t_steps, e, a), dtype=torch.float32, device=dev),
+                terminated=torch.empty((t_steps, e, a), dtype=torch.uint8, device=dev),
+                truncated=torch.empty((t_steps, e, a), dtype=torch.uint8, device=dev),
+                onehot=torch.empty((t_steps, e, a, v, v, _lib.ONE_HOT_DIM), dtype=torch.uint8, device=dev)
+                if one_hot else None)
+        elif any(t is not None and t.shape[0] != t_steps for t in
+                 (out.image, out.direction, out.reward, out.terminated, out.truncated, out.onehot)):
+            raise ValueError("out must hold one slice per step")
+        mo = self._make_out(out)
+        check(_lib.lib().mg_step_n(self._h, t_steps, _ptr(act), _ptr(od), ctypes.byref(mo), self._stream()), self._h)
+        return out
 
     def gen_obs(self, out: Optional[StepOutput] = None) -> StepOutput:
         """``MultiGridEnv.gen_obs`` (multigrid/base.py:410)."""

@@ -116,6 +116,7 @@ struct KParams {
     const uint8_t *mask;
     // outputs
     uint8_t *image;
+    uint8_t *onehot;
     uint8_t *direction;
     float *reward;
     uint8_t *terminated;
@@ -996,6 +997,65 @@ __device__ __forceinline__ void observe_agent(const KParams &p, uint2 row, const
     px[3 * (V * V / 4)] = cell[V * V - 1];
 }
 
+// ---- one-hot images ----------------------------------------------------------------------------------
+//
+// OneHotObsWrapper.one_hot, multigrid/wrappers.py:114-146, with dim_sizes = (11 types, 6 colours,
+// 7 states) of wrappers.py:95: a cell (t, c, s) becomes 24 bytes with ones at t, 11 + c and 17 + s.
+// The 24 bytes are three little-endian 64-bit words; a one at byte k of the cell is 1 << 8k taken
+// modulo 64 and routed to the word k / 8.  Values the reference cannot produce set a byte only
+// while it stays inside the cell's 24.
+constexpr int OH_DIM = 24;
+
+__device__ __forceinline__ void one_hot_cell(uint32_t tcs, uint64_t &lo, uint64_t &mid, uint64_t &hi) {
+    const uint32_t t = tcs & 0xFF, c = (tcs >> 8) & 0xFF, s = (tcs >> 16) & 0xFF;
+    const uint64_t x = 1ull << ((8 * t) & 63);        // byte t
+    const uint64_t y = 1ull << ((8 * (c + 3)) & 63);  // byte 11 + c
+    const uint64_t z = 1ull << ((8 * (s + 1)) & 63);  // byte 17 + s
+    lo = t < 8 ? x : 0ull;
+    mid = ((t >= 8 && t < 16) ? x : 0ull) | (c < 5 ? y : 0ull);
+    hi = ((c >= 5 && c < 13) ? y : 0ull) | (s < 7 ? z : 0ull);
+}
+
+// `n_cells` consecutive cells of the image stream at `src` (LDS, three bytes per cell) expanded to
+// `dst` (8-byte aligned).  Cell k belongs to agent first_agent + k / (V * V) of the sub-tile; cells of
+// environments outside `slot_mask` are skipped.  With every environment taking part and a 16-byte
+// aligned destination, each lane expands two cells into three 16-byte stores.
+template <int V>
+__device__ __forceinline__ void emit_one_hot(const KParams &p, const uint8_t *src, int n_cells, uint8_t *dst,
+                                             int lane, bool all, uint64_t slot_mask, int first_agent) {
+    if (all && (n_cells & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+        const uint16_t *s16 = reinterpret_cast<const uint16_t *>(src);
+        const int pairs = n_cells / 2;
+#pragma unroll 2
+        for (int j = lane; j < pairs; j += 64) {
+            const uint32_t a = s16[3 * j], b = s16[3 * j + 1], c = s16[3 * j + 2];
+            uint64_t l0, m0, h0, l1, m1, h1;
+            one_hot_cell(a | ((b & 0xFFu) << 16), l0, m0, h0);
+            one_hot_cell((b >> 8) | (c << 8), l1, m1, h1);
+            uint4 *d = reinterpret_cast<uint4 *>(dst + 2 * OH_DIM * j);
+            d[0] = make_uint4(static_cast<uint32_t>(l0), static_cast<uint32_t>(l0 >> 32), static_cast<uint32_t>(m0),
+                              static_cast<uint32_t>(m0 >> 32));
+            d[1] = make_uint4(static_cast<uint32_t>(h0), static_cast<uint32_t>(h0 >> 32), static_cast<uint32_t>(l1),
+                              static_cast<uint32_t>(l1 >> 32));
+            d[2] = make_uint4(static_cast<uint32_t>(m1), static_cast<uint32_t>(m1 >> 32), static_cast<uint32_t>(h1),
+                              static_cast<uint32_t>(h1 >> 32));
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int k = lane; k < n_cells; k += 64) {
+        const int slot = udiv(first_agent + k / (V * V), p.magic_a);
+        if (!((slot_mask >> slot) & 1)) continue;
+        const uint8_t *b = src + 3 * k;
+        uint64_t l0, m0, h0;
+        one_hot_cell(b[0] | (static_cast<uint32_t>(b[1]) << 8) | (static_cast<uint32_t>(b[2]) << 16), l0, m0, h0);
+        uint64_t *d = reinterpret_cast<uint64_t *>(dst + static_cast<size_t>(OH_DIM) * k);
+        d[0] = l0;
+        d[1] = m0;
+        d[2] = h0;
+    }
+}
+
 #ifdef MGRID_EXPERIMENT
 // Diagnostic build only: drain memory, read the shader clock, keep it in a buffer of its own.
 #define MG_STAMP(k)                                                                        \
@@ -1021,7 +1081,7 @@ __device__ __forceinline__ void observe_agent(const KParams &p, uint2 row, const
 // the whole launch; grids are brought in NE environments ("sub-tile", NE * A <= 64 agent lanes)
 // at a time for the observation passes.
 
-template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED>
+template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH>
 __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int IMG = 3 * V * V;  // bytes per agent image
@@ -1046,7 +1106,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     if (active_mask == 0) return;
 
     const int per = p.GS / 16;
-    const bool want_img = p.image != nullptr;
+    const bool want_img = p.image != nullptr || (OH && p.onehot != nullptr);
 #ifdef MGRID_EXPERIMENT
     const bool passes = (want_img || MODE == MODE_STEP) && !(p.dbg & 32);
 #else
@@ -1339,12 +1399,13 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
             // Images leave through a small LDS buffer, STAGE_LANES agents at a time: their lanes lay the
             // byte streams down back to back, then the whole wavefront stores the block as 16-byte pieces.
             // The stream sits `shift` bytes into the buffer so that LDS and HBM agree modulo 16.
-            const size_t tile_base = (static_cast<size_t>(e0 + s0) * A) * IMG;  // byte offset of the sub-tile's images
+            const size_t tile_agent0 = static_cast<size_t>(e0 + s0) * A;  // first agent of the sub-tile
+            const size_t tile_base = tile_agent0 * IMG;  // byte offset of the sub-tile's images
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 2))
 #endif
             if (want_img && all_active && np % STAGE_LANES == 0 &&
-                ((reinterpret_cast<uintptr_t>(p.image) + tile_base) & 15) == 0) {
+                (p.image == nullptr || ((reinterpret_cast<uintptr_t>(p.image) + tile_base) & 15) == 0)) {
                 // whole blocks, 16-byte aligned in HBM (STAGE_LANES * IMG is a multiple of 16)
                 constexpr int CH = STAGE_LANES * IMG / 16;  // 16-byte pieces per block
                 constexpr int MAXIT = (CH + 63) / 64;
@@ -1376,12 +1437,18 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                             if (j < 3) wdst[M] = px[M];
                         }
                         wave_sync();
-                        uint4 ob[MAXIT];  // all LDS reads first, then all stores
+                        if (p.image) {
+                            uint4 ob[MAXIT];  // all LDS reads first, then all stores
 #pragma unroll
-                        for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, CH - 1)];
+                            for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, CH - 1)];
 #pragma unroll
-                        for (int it = 0; it < MAXIT; ++it)
-                            if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it];
+                            for (int it = 0; it < MAXIT; ++it)
+                                if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it];
+                        }
+                        if (OH && p.onehot)
+                            emit_one_hot<V>(p, lds + p.o.img, STAGE_LANES * V * V,
+                                            p.onehot + (tile_agent0 + r * STAGE_LANES) * (OH_DIM * V * V), lane, true, ~0ull,
+                                            r * STAGE_LANES);
                         wave_sync();
                     }
                 }
@@ -1390,7 +1457,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                 for (int l0 = 0; l0 < np; l0 += STAGE_LANES) {
                     const int nl = min(STAGE_LANES, np - l0);
                     const size_t out_base = tile_base + static_cast<size_t>(l0) * IMG;  // byte offset of the block
-                    const int shift = static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15);
+                    const int shift = p.image ? static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15) : 0;
                     if (mine && lane >= l0 && lane < l0 + nl) {
                         uint8_t *dst = lds + p.o.img + shift + (lane - l0) * IMG;
 #pragma unroll
@@ -1401,7 +1468,10 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                     wave_sync();
                     uint8_t *gdst = p.image + out_base - shift;
                     const int total = shift + nl * IMG;
-                    const int nchunk = (total + 15) / 16;
+                    const int nchunk = p.image ? (total + 15) / 16 : 0;
+                    if (OH && p.onehot)
+                        emit_one_hot<V>(p, lds + p.o.img + shift, nl * V * V,
+                                        p.onehot + (tile_agent0 + l0) * (OH_DIM * V * V), lane, false, sub_mask, l0);
 #pragma unroll 1
                     for (int c = lane; c < nchunk; c += 64) {
                         const int b0 = 16 * c;
@@ -1609,26 +1679,29 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int V, int MODE, bool WALLED>
+template <int V, int MODE, bool WALLED, bool OH>
 void launch_vmw(const MgEnv *h, const KParams &kp, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
     const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
     if (see && small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
     else if (see)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
     else if (small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
     else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
 }
 
 template <int V, int MODE>
 void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
-    if (kp.walled())
-        launch_vmw<V, MODE, true>(h, kp, s);
+    // launches that also write one-hot images are bound by those stores; they share the general-border code
+    if (kp.onehot)
+        launch_vmw<V, MODE, false, true>(h, kp, s);
+    else if (kp.walled())
+        launch_vmw<V, MODE, true, false>(h, kp, s);
     else
-        launch_vmw<V, MODE, false>(h, kp, s);
+        launch_vmw<V, MODE, false, false>(h, kp, s);
 }
 
 template <int MODE>
@@ -1643,8 +1716,13 @@ int launch_tile(MgEnv *h, const KParams &kp, hipStream_t s) {
     return MG_OK;
 }
 
+bool out_ok(const MgOut *out) {  // the one-hot image is written in 8-byte pieces
+    return !out || (reinterpret_cast<uintptr_t>(out->onehot_dev) & 7) == 0;
+}
+
 void set_out(KParams &kp, const MgOut *out) {
     kp.image = out ? out->image_dev : nullptr;
+    kp.onehot = out ? out->onehot_dev : nullptr;
     kp.direction = out ? out->direction_dev : nullptr;
     kp.reward = out ? out->reward_dev : nullptr;
     kp.terminated = out ? out->terminated_dev : nullptr;
@@ -1853,6 +1931,7 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
 int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev, const MgOut *out, void *stream) {
     if (!h) return MG_EINVAL;
     if (h->num_layouts < 1) return fail(h, MG_ESTATE, "mg_reset: no layouts uploaded");
+    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_reset: onehot_dev must be 8-byte aligned");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
     kp.layout_idx = layout_idx_dev;
@@ -1871,6 +1950,7 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
 int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out, void *stream) {
     if (!h) return MG_EINVAL;
     if (!actions_dev) return fail(h, MG_EINVAL, "mg_step: actions_dev is null");
+    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_step: onehot_dev must be 8-byte aligned");
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_step: call mg_reset (or mg_set_state) first");
     if (h->cfg.autoreset != MG_AUTORESET_NONE && h->num_layouts < 1)
         return fail(h, MG_ESTATE, "mg_step: autoreset needs uploaded layouts");
@@ -1887,9 +1967,35 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
     return MG_OK;
 }
 
+int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out,
+              void *stream) {
+    if (!h) return MG_EINVAL;
+    if (num_steps < 1) return fail(h, MG_EINVAL, "mg_step_n: num_steps must be positive");
+    // one launch per step, all queued on the stream by this one call; step t reads slice t of the
+    // inputs and writes slice t of every output
+    const size_t per = static_cast<size_t>(h->kp.E) * h->kp.A();
+    const size_t img = 3u * h->cfg.view_size * h->cfg.view_size;
+    for (int32_t t = 0; t < num_steps; ++t) {
+        MgOut o{};
+        if (out) {
+            o.image_dev = out->image_dev ? out->image_dev + t * per * img : nullptr;
+            o.onehot_dev = out->onehot_dev ? out->onehot_dev + t * per * img * (OH_DIM / 3) : nullptr;
+            o.direction_dev = out->direction_dev ? out->direction_dev + t * per : nullptr;
+            o.reward_dev = out->reward_dev ? out->reward_dev + t * per : nullptr;
+            o.terminated_dev = out->terminated_dev ? out->terminated_dev + t * per : nullptr;
+            o.truncated_dev = out->truncated_dev ? out->truncated_dev + t * per : nullptr;
+        }
+        const int rc = mg_step(h, actions_dev ? actions_dev + t * per : nullptr, order_dev ? order_dev + t * per : nullptr,
+                               out ? &o : nullptr, stream);
+        if (rc != MG_OK) return rc;
+    }
+    return MG_OK;
+}
+
 int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
     if (!h) return MG_EINVAL;
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_gen_obs: call mg_reset (or mg_set_state) first");
+    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_gen_obs: onehot_dev must be 8-byte aligned");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
     set_out(kp, out);

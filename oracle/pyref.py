@@ -244,6 +244,35 @@ def gen_obs_fast(grid, agents, v: int, see_through_walls: bool) -> np.ndarray:
 
 # --- environment ---------------------------------------------------------------
 
+# --- OneHotObsWrapper (multigrid/wrappers.py:60-146) ---------------------------
+# dim_sizes of wrappers.py:95: len(Type), len(Color), max(len(State), len(Direction))
+ONE_HOT_DIMS = (11, 6, 7)
+
+
+def one_hot(x: np.ndarray, dim_sizes: Sequence[int] = ONE_HOT_DIMS) -> np.ndarray:
+    """``OneHotObsWrapper.one_hot`` (multigrid/wrappers.py:114-146), loop for loop: every 2D slice
+    ``x[:, :, d]`` is encoded on its own run of ``dim_sizes[d]`` channels."""
+    out = np.zeros((x.shape[0], x.shape[1], sum(dim_sizes)), dtype=np.uint8)
+    dim_offset = 0
+    for d in range(len(dim_sizes)):
+        for i in range(x.shape[0]):
+            for j in range(x.shape[1]):
+                out[i, j, dim_offset + x[i, j, d]] = 1  # wrappers.py:141-142
+        dim_offset += dim_sizes[d]
+    return out
+
+
+def one_hot_batch(images: np.ndarray, dim_sizes: Sequence[int] = ONE_HOT_DIMS) -> np.ndarray:
+    """``one_hot`` over any number of leading dimensions (``[..., V, V, 3] -> [..., V, V, 24]``)."""
+    images = np.asarray(images)
+    out = np.zeros(images.shape[:-1] + (sum(dim_sizes),), dtype=np.uint8)
+    dim_offset = 0
+    for d, n in enumerate(dim_sizes):
+        np.put_along_axis(out, (dim_offset + images[..., d:d + 1]).astype(np.int64), 1, axis=-1)
+        dim_offset += n
+    return out
+
+
 class Env:
     """One environment, stepped the way ``MultiGridEnv`` is (multigrid/base.py:37)."""
 

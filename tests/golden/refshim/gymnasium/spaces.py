@@ -55,6 +55,9 @@ class Dict(Space):
     def __getitem__(self, k):
         return self.spaces[k]
 
+    def __setitem__(self, k, v):
+        self.spaces[k] = v
+
     def keys(self):
         return self.spaces.keys()
 

@@ -13,7 +13,13 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def group_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0]
                    for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if n != "layouts"]
+    return [n for n in names if n not in ("layouts", "onehot")]
+
+
+def load_onehot_fixture():
+    """One-hot encodings recorded from the reference's OneHotObsWrapper (tests/golden/make_golden_onehot.py)."""
+    with np.load(os.path.join(GOLDEN_DIR, "onehot.npz")) as z:
+        return {k: z[k] for k in z.files}
 
 
 def load_group(name):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.mg_abi_version() == 1
+    assert lib.mg_abi_version() == _lib.ABI_VERSION
 
 
 def test_bad_arguments_fail_without_a_gpu():
