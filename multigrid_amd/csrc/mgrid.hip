@@ -61,7 +61,10 @@ constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 #endif
 // With few agents per environment the in-order replay (one lane per environment) is cheaper than the
 // lane-per-agent pass plus its bookkeeping; measured crossover on MI355X.
-constexpr int PARALLEL_ACT_MIN_AGENTS = 6;
+#ifndef MG_PARALLEL_ACT_MIN_AGENTS
+#define MG_PARALLEL_ACT_MIN_AGENTS 6
+#endif
+constexpr int PARALLEL_ACT_MIN_AGENTS = MG_PARALLEL_ACT_MIN_AGENTS;
 constexpr int STAGE_LANES = MG_STAGE_LANES;  // agents whose images share the LDS staging buffer; a multiple of 16
 
 struct LdsMap {
@@ -77,6 +80,7 @@ struct LdsMap {
     int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
     int grid;   // [NE][GS]      grids of the sub-tile being observed
     int img;    // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order
+    int oh;     // [192] uint4   one-hot pieces changing lanes (present only in launches that write one-hot images)
 };
 
 struct KParams {
@@ -225,6 +229,9 @@ enum : uint32_t {
     EV_BOX = 128u, EV_BLUE = 256u, EV_GOAL = 512u, EV_TERM = 1024u, EV_WRITE = 2048u,
     EV_MAY_WRITE = EV_DROP | EV_PK | EV_UNLOCK | EV_FLIP | EV_BOX,
 };
+
+// bit of an environment's word in the LDS `flag` array: act_lanes() has finished the whole step
+constexpr uint32_t ACT_FINISHED = 1u << 25;
 
 struct ActEval {
     uint2 r;        // the agent's row after the action
@@ -377,6 +384,7 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     const uint8_t *actb = lds + p.o.act + slot * A;
     uint8_t *ordb = lds + p.o.ord + slot * A;
 
+    if (*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot) & ACT_FINISHED) return;
     const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
     const int step = static_cast<int>(h0.x) + 1;  // base.py:395
     *reinterpret_cast<int *>(h + H_STEP) = step;
@@ -616,6 +624,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
     const uint64_t ones = 0x0101010101010101ull >> (8 * (8 - A));  // byte k = 1 for k < A
 
+    if (*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot) & ACT_FINISHED) return;
     const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
     const int step = static_cast<int>(h0.x) + 1;  // base.py:395
     *reinterpret_cast<int *>(h + H_STEP) = step;
@@ -801,8 +810,8 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 // of that cell.  Such environments are left untouched for the replay in act_env*(); for the others
 // the result is final here, whatever the order.  Runs on the NE environments from `s0`; the scratch
 // array lives in the image staging area, which is idle during the act phase.
-__device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int s0, int ns, int lane, int my_slot,
-                                          int my_agent) {
+__device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int env0, int s0, int ns, int lane,
+                                          int my_slot, int my_agent) {
     const int A = p.A();
     const bool mine = lane < ns * A;
     uint8_t *h = lds + p.o.hdr + (s0 + my_slot) * p.HS;
@@ -854,9 +863,52 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int s0
         lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>((r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u));
         lds[p.o.rewm + s0 * A + lane] = (ev.bits & EV_GOAL) ? 1 : 0;  // base.py:558-562
     }
-    if (mine && my_agent == 0)  // picked up by act_env*()
+    if (p.kind() == MG_KIND_EMPTY) {
+        // No environment hook: the rest of the step (multigrid/base.py:395-402 plus the bookkeeping of
+        // act_env*()) is done here, the environment's lanes agreeing through ballots.
+        const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | meta
+        const int step = static_cast<int>(h0.x) + 1;           // base.py:395
+        const uint32_t my_term = (r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u);
+        const uint64_t goals = __ballot(final_here && (ev.bits & EV_GOAL)) & group;
+        const bool all_term = (__ballot(final_here && my_term != 0) & group) == group;
+        const bool trunc = step >= p.max_steps;  // base.py:401-402
+        const bool over = trunc || all_term;
+        const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
+        if (final_here) {
+            lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_term);  // base.py:400
+            if (p.joint()) lds[p.o.rewm + s0 * A + lane] = goals ? 1 : 0;   // base.py:558-559
+            // a cell changed by this step goes back to HBM unless the whole grid is about to be replaced
+            if (wr && !will_reset)
+                reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
+                    static_cast<uint16_t>(ev.nv);
+            if (my_agent == 0) {
+                const double R = 1.0 - static_cast<double>(step) * p.reward_slope;  // base.py:655-659
+                const uint32_t flags = h0.z & 0xFF;
+                *reinterpret_cast<int *>(h + H_STEP) = step;
+                h[H_FLAGS] = static_cast<uint8_t>(flags | (over ? FLAG_OVER : 0u));
+                reinterpret_cast<double *>(lds + p.o.R)[s0 + my_slot] = R;
+                *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) =
+                    (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) |
+                    ACT_FINISHED;
+                // episode statistics: touched only when something happened (rare)
+                int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
+                if (over && !(flags & FLAG_OVER)) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+                }
+                const int paid = goals ? (p.joint() ? A : __popcll(goals)) : 0;
+                if (paid != 0)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+                              static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
+            }
+        } else if (mine && my_agent == 0) {
+            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = 0x100u;  // replay in act_env*()
+        }
+    } else if (mine && my_agent == 0) {  // picked up by act_env*()
         *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) =
             (replay ? 0x100u : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) | (resync ? 1u << 24 : 0u);
+    }
     wave_sync();
 }
 
@@ -1019,26 +1071,44 @@ __device__ __forceinline__ void one_hot_cell(uint32_t tcs, uint64_t &lo, uint64_
 // `n_cells` consecutive cells of the image stream at `src` (LDS, three bytes per cell) expanded to
 // `dst` (8-byte aligned).  Cell k belongs to agent first_agent + k / (V * V) of the sub-tile; cells of
 // environments outside `slot_mask` are skipped.  With every environment taking part and a 16-byte
-// aligned destination, each lane expands two cells into three 16-byte stores.
+// aligned destination, each lane expands two cells (48 bytes); the pieces then change lanes through
+// LDS so that every store instruction of the wavefront covers one contiguous KiB.
+constexpr int OH_XCHG_BYTES = 64 * 2 * OH_DIM;
+
 template <int V>
-__device__ __forceinline__ void emit_one_hot(const KParams &p, const uint8_t *src, int n_cells, uint8_t *dst,
-                                             int lane, bool all, uint64_t slot_mask, int first_agent) {
+__device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, const uint8_t *src, int n_cells,
+                                             uint8_t *dst, int lane, bool all, uint64_t slot_mask, int first_agent) {
     if (all && (n_cells & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
         const uint16_t *s16 = reinterpret_cast<const uint16_t *>(src);
+        uint4 *xb = reinterpret_cast<uint4 *>(lds + p.o.oh);
         const int pairs = n_cells / 2;
-#pragma unroll 2
-        for (int j = lane; j < pairs; j += 64) {
-            const uint32_t a = s16[3 * j], b = s16[3 * j + 1], c = s16[3 * j + 2];
-            uint64_t l0, m0, h0, l1, m1, h1;
-            one_hot_cell(a | ((b & 0xFFu) << 16), l0, m0, h0);
-            one_hot_cell((b >> 8) | (c << 8), l1, m1, h1);
-            uint4 *d = reinterpret_cast<uint4 *>(dst + 2 * OH_DIM * j);
-            d[0] = make_uint4(static_cast<uint32_t>(l0), static_cast<uint32_t>(l0 >> 32), static_cast<uint32_t>(m0),
-                              static_cast<uint32_t>(m0 >> 32));
-            d[1] = make_uint4(static_cast<uint32_t>(h0), static_cast<uint32_t>(h0 >> 32), static_cast<uint32_t>(l1),
-                              static_cast<uint32_t>(l1 >> 32));
-            d[2] = make_uint4(static_cast<uint32_t>(m1), static_cast<uint32_t>(m1 >> 32), static_cast<uint32_t>(h1),
-                              static_cast<uint32_t>(h1 >> 32));
+#pragma unroll 1
+        for (int j0 = 0; j0 < pairs; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < pairs) {
+                const uint32_t a = s16[3 * j], b = s16[3 * j + 1], c = s16[3 * j + 2];
+                uint64_t l0, m0, h0, l1, m1, h1;
+                one_hot_cell(a | ((b & 0xFFu) << 16), l0, m0, h0);
+                one_hot_cell((b >> 8) | (c << 8), l1, m1, h1);
+                uint4 *d = xb + 3 * lane;
+                d[0] = make_uint4(static_cast<uint32_t>(l0), static_cast<uint32_t>(l0 >> 32), static_cast<uint32_t>(m0),
+                                  static_cast<uint32_t>(m0 >> 32));
+                d[1] = make_uint4(static_cast<uint32_t>(h0), static_cast<uint32_t>(h0 >> 32), static_cast<uint32_t>(l1),
+                                  static_cast<uint32_t>(l1 >> 32));
+                d[2] = make_uint4(static_cast<uint32_t>(m1), static_cast<uint32_t>(m1 >> 32), static_cast<uint32_t>(h1),
+                                  static_cast<uint32_t>(h1 >> 32));
+            }
+            wave_sync();
+            const int pieces = 3 * min(64, pairs - j0);
+            uint4 *out = reinterpret_cast<uint4 *>(dst + static_cast<size_t>(2 * OH_DIM) * j0);
+            uint4 q0, q1, q2;
+            q0 = xb[min(lane, pieces - 1)];
+            q1 = xb[min(64 + lane, pieces - 1)];
+            q2 = xb[min(128 + lane, pieces - 1)];
+            if (lane < pieces) out[lane] = q0;
+            if (64 + lane < pieces) out[64 + lane] = q1;
+            if (128 + lane < pieces) out[128 + lane] = q2;
+            wave_sync();
         }
         return;
     }
@@ -1239,7 +1309,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     if (MODE == MODE_STEP) {
         if (A >= PARALLEL_ACT_MIN_AGENTS) {
 #pragma unroll 1
-            for (int s0 = 0; s0 < net; s0 += NE) act_lanes(p, lds, s0, min(NE, net - s0), lane, my_slot, my_agent);
+            for (int s0 = 0; s0 < net; s0 += NE) act_lanes(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
         } else if (lane < net) {
             *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = 0x100u;  // replay every environment in order
         }
@@ -1248,7 +1318,9 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         MG_TICK(ta1);
         const int n_replay = __popcll(__ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0));
 #endif
-        if (lane < net) {
+        // environments that act_lanes() could not finish: hooks, or agents whose actions interact
+        if (__ballot(lane < net && !(*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * lane) & ACT_FINISHED)) != 0 &&
+            lane < net) {
             if constexpr (small)
                 act_env_small(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
                               p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
@@ -1446,7 +1518,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                                 if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it];
                         }
                         if (OH && p.onehot)
-                            emit_one_hot<V>(p, lds + p.o.img, STAGE_LANES * V * V,
+                            emit_one_hot<V>(p, lds, lds + p.o.img, STAGE_LANES * V * V,
                                             p.onehot + (tile_agent0 + r * STAGE_LANES) * (OH_DIM * V * V), lane, true, ~0ull,
                                             r * STAGE_LANES);
                         wave_sync();
@@ -1470,7 +1542,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
                     const int total = shift + nl * IMG;
                     const int nchunk = p.image ? (total + 15) / 16 : 0;
                     if (OH && p.onehot)
-                        emit_one_hot<V>(p, lds + p.o.img + shift, nl * V * V,
+                        emit_one_hot<V>(p, lds, lds + p.o.img + shift, nl * V * V,
                                         p.onehot + (tile_agent0 + l0) * (OH_DIM * V * V), lane, false, sub_mask, l0);
 #pragma unroll 1
                     for (int c = lane; c < nchunk; c += 64) {
@@ -1680,17 +1752,20 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int V, int MODE, bool WALLED, bool OH>
-void launch_vmw(const MgEnv *h, const KParams &kp, hipStream_t s) {
+void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
+    KParams kp = kp_in;
+    kp.o.oh = static_cast<int>(h->lds_bytes);  // the exchange buffer follows everything else
+    const size_t lds = h->lds_bytes + (OH ? OH_XCHG_BYTES : 0);
     const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
     if (see && small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH>), grid, block, lds, s, kp);
     else if (see)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED, OH>), grid, block, lds, s, kp);
     else if (small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH>), grid, block, lds, s, kp);
     else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED, OH>), grid, block, h->lds_bytes, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED, OH>), grid, block, lds, s, kp);
 }
 
 template <int V, int MODE>
@@ -1824,7 +1899,7 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         if (kp.dbg & 32) h->lds_bytes = static_cast<size_t>(kp.o.grid);  // act phase alone
     }
 #endif
-    if (h->lds_bytes > 64 * 1024) {
+    if (h->lds_bytes + OH_XCHG_BYTES > 64 * 1024) {
         const size_t need = h->lds_bytes;
         delete h;
         return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", need);

@@ -1,0 +1,109 @@
+"""Vector-environment view of one ``BatchedMultiGrid``: N environments behind one ``reset`` / ``step``.
+
+This is the contract of ``gymnasium.vector.SyncVectorEnv`` as the reference uses it
+(multigrid/scripts/train_ppo_cleanrl.py:366 builds it, :517-529 steps it and reads
+``info["final_info"][i]["episode"]["r" / "l"]`` left there by ``RecordEpisodeStatistics``, :173):
+
+* ``step`` never needs a ``reset`` call in between: an environment whose episode ended
+  (``all(terminations)`` or truncation, multigrid/base.py:587-596) restarts inside the same launch,
+  the observation returned for it is the first one of its next episode, and reward / terminated /
+  truncated are those of the step that ended the episode;
+* ``infos["_final_info"]`` marks those environments and ``infos["final_info"][i]`` holds
+  ``{"episode": {"r": return, "l": length}}`` for them (``None`` elsewhere).  The same numbers
+  are available without leaving the device as ``infos["episode_return"]`` / ``["episode_length"]``.
+
+Every array is a PyTorch-ROCm tensor written in place by the HIP kernels (``numpy=True`` converts
+at the boundary like ``SyncVectorEnv`` does).  With ``single_agent=True`` (one agent per
+environment, the ``SingleAgentWrapper`` case of multigrid/wrappers.py:149-176) the agent
+dimension is dropped, which is the exact ``SyncVectorEnv`` shape; otherwise arrays are ``[N, A, ...]``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, envs, layouts
+from .batched import BatchedMultiGrid
+
+
+class MultiGridVectorEnv:
+    def __init__(self, name: str, num_envs: int, agents: Optional[int] = None, device: int | str = 0,
+                 num_layouts: int = 1024, seed: int = 0, one_hot: bool = False, single_agent: bool = False,
+                 numpy: bool = False, env_id_offset: int = 0, **kwargs):
+        self.spec, self._gen = envs.make_spec(name, num_agents=agents, **kwargs)
+        self.num_envs = int(num_envs)
+        self.num_agents = self.spec["num_agents"]
+        if single_agent and self.num_agents != 1:
+            raise ValueError("single_agent=True needs agents=1")
+        self.single_agent, self.one_hot, self.numpy = single_agent, one_hot, numpy
+        self.num_actions = 7  # multigrid/core/actions.py:4-15
+        self._sim = BatchedMultiGrid(self.spec, self.num_envs, device=device, autoreset=_lib.AUTORESET_SAME_STEP,
+                                     env_id_offset=env_id_offset, seed=seed, one_hot=one_hot)
+        self._num_layouts, self._seed = int(num_layouts), int(seed)
+        self._uploaded = None
+        dev = self._sim.device
+        self._ret = torch.zeros((self.num_envs, self.num_agents), dtype=torch.float64, device=dev)
+        self._len = torch.zeros((self.num_envs,), dtype=torch.int64, device=dev)
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _view(self, t: torch.Tensor):
+        if self.single_agent:
+            t = t[:, 0]
+        return t.cpu().numpy() if self.numpy else t
+
+    def _obs(self, out):
+        return {"image": self._view(out.onehot if self.one_hot else out.image), "direction": self._view(out.direction)}
+
+    def _layouts(self, seed: int):
+        if self._uploaded != seed:
+            grids, ags, metas, _ = layouts.make_pool(self._gen, self._num_layouts, seed0=seed)
+            self._sim.upload_layouts(grids, ags, metas)
+            self._uploaded = seed
+
+    # -- SyncVectorEnv surface -----------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options=None):
+        """Start every environment on a fresh episode.  ``seed`` selects the pool of start states (layout k of
+        the pool is drawn with generator seed ``seed + k``); without it the pool of the last reset is kept."""
+        self._layouts(self._seed if seed is None else int(seed))
+        out = self._sim.reset()
+        self._ret.zero_()
+        self._len.zero_()
+        return self._obs(out), {}
+
+    def step(self, actions):
+        a = torch.as_tensor(actions)
+        if self.single_agent and a.dim() == 1:
+            a = a[:, None]
+        out = self._sim.step(a.to(torch.uint8))
+        # RecordEpisodeStatistics, one set of counters per environment
+        self._ret += out.reward
+        self._len += 1
+        done = out.terminated.bool().all(dim=1) | out.truncated.bool()[:, 0]
+        infos = {}
+        if bool(done.any()):
+            ep_ret = torch.where(done[:, None], self._ret, torch.zeros_like(self._ret))
+            ep_len = torch.where(done, self._len, torch.zeros_like(self._len))
+            infos["_final_info"] = self._view_mask(done)
+            infos["episode_return"] = self._view(ep_ret)
+            infos["episode_length"] = ep_len.cpu().numpy() if self.numpy else ep_len
+            final = np.full((self.num_envs,), None, dtype=object)
+            idx = done.nonzero()[:, 0].cpu().numpy()
+            r, l = ep_ret[idx].cpu().numpy(), ep_len[idx].cpu().numpy()
+            for k, i in enumerate(idx):
+                final[i] = {"episode": {"r": float(r[k, 0]) if self.single_agent else r[k], "l": int(l[k])}}
+            infos["final_info"] = final
+            self._ret.masked_fill_(done[:, None], 0.0)
+            self._len.masked_fill_(done, 0)
+        return (self._obs(out), self._view(out.reward), self._view(out.terminated.bool()),
+                self._view(out.truncated.bool()), infos)
+
+    def _view_mask(self, done):
+        return done.cpu().numpy() if self.numpy else done
+
+    def stats(self) -> torch.Tensor:
+        return self._sim.stats()
+
+    def close(self):
+        self._sim.close()

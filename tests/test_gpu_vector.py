@@ -1,0 +1,85 @@
+"""The SyncVectorEnv-style adapter: same-step auto-reset, final_info episode statistics, against the C oracle."""
+import numpy as np
+import pytest
+
+from multigrid_amd import envs, layouts
+
+pytestmark = pytest.mark.gpu
+
+LAYOUT_STRIDE = 7919
+
+
+def device_order_for(seed, gid, episode, step, a):
+    from test_gpu_batch import device_order
+    return device_order(seed, gid, episode, step, a)
+
+
+@pytest.mark.parametrize("name,agents,single,kw", [
+    ("MultiGrid-BlockedUnlockPickup-v0", 1, True, dict(max_steps=40)),
+    ("MultiGrid-LockedHallway-2Rooms-v0", 3, False, dict(max_steps=35)),
+    ("MultiGrid-Empty-6x6-v0", 2, False, dict(max_steps=24)),
+])
+def test_vector_env_contract(name, agents, single, kw):
+    import torch
+    from multigrid_amd.vector import MultiGridVectorEnv
+    from oracle.coracle import BatchOracle
+    from oracle import pyref
+
+    n, n_layouts, seed = 700, 48, 21
+    venv = MultiGridVectorEnv(name, n, agents=agents, device=0, num_layouts=n_layouts, seed=seed,
+                              single_agent=single, numpy=True, one_hot=True, **kw)
+    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+    pool = layouts.make_pool(gen, n_layouts, seed0=seed)
+    ora = BatchOracle(spec, n)
+    ids_all = np.arange(n)
+    episode = np.zeros(n, np.int64)
+    obs, infos = venv.reset()
+    assert infos == {}
+    idx = (ids_all + LAYOUT_STRIDE * episode) % n_layouts
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    squeeze = (lambda x: x[:, 0]) if single else (lambda x: x)
+    np.testing.assert_array_equal(obs["image"], squeeze(pyref.one_hot_batch(ora.gen_obs())))
+    rng = np.random.default_rng(3)
+    ret = np.zeros((n, agents))
+    length = np.zeros(n, np.int64)
+    finished = 0
+    for t in range(90):
+        actions = rng.integers(0, 7, size=(n, agents)).astype(np.uint8)
+        order = device_order_for(seed, ids_all, episode, ora.steps + 1, agents)
+        obs, rew, term, trunc, infos = venv.step(actions[:, 0] if single else actions)
+        img, direction, r, tm, tr = ora.step(actions, order)
+        img, direction = img.copy(), direction.copy()
+        ret += r
+        length += 1
+        done = tm.all(axis=1) | tr.all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            finished += len(ids)
+            assert np.array_equal(infos["_final_info"], done)
+            for i in range(n):
+                if done[i]:
+                    ep = infos["final_info"][i]["episode"]
+                    assert ep["l"] == length[i]
+                    np.testing.assert_allclose(np.atleast_1d(ep["r"]), ret[i], rtol=0, atol=1e-5)
+                else:
+                    assert infos["final_info"][i] is None
+            np.testing.assert_allclose(infos["episode_return"], squeeze(np.where(done[:, None], ret, 0.0)), atol=1e-5)
+            np.testing.assert_array_equal(infos["episode_length"], np.where(done, length, 0))
+            ret[ids] = 0
+            length[ids] = 0
+            episode[ids] += 1
+            idx = (ids + LAYOUT_STRIDE * episode[ids]) % n_layouts
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+            img[ids] = ora.gen_obs()[ids]
+            direction[ids] = ora.agents[ids, :, 2]
+        else:
+            assert infos == {}
+        where = f"{name} step {t}"
+        np.testing.assert_array_equal(obs["image"], squeeze(pyref.one_hot_batch(img)), err_msg=where)
+        np.testing.assert_array_equal(obs["direction"], squeeze(direction), err_msg=where)
+        np.testing.assert_allclose(rew, squeeze(r), rtol=0, atol=1e-6, err_msg=where)
+        np.testing.assert_array_equal(term, squeeze(tm.astype(bool)), err_msg=where)
+        np.testing.assert_array_equal(trunc, squeeze(tr.astype(bool)), err_msg=where)
+    assert finished >= n  # every environment was truncated at least once
+    assert obs["image"].shape == ((n, 7, 7, 24) if single else (n, agents, 7, 7, 24))
+    venv.close()
