@@ -228,10 +228,16 @@ enum : uint32_t {
     EV_ALIVE = 1u, EV_ONCELL = 2u, EV_FWD = 4u, EV_DROP = 8u, EV_PK = 16u, EV_UNLOCK = 32u, EV_FLIP = 64u,
     EV_BOX = 128u, EV_BLUE = 256u, EV_GOAL = 512u, EV_TERM = 1024u, EV_WRITE = 2048u,
     EV_MAY_WRITE = EV_DROP | EV_PK | EV_UNLOCK | EV_FLIP | EV_BOX,
+    // what the action could do if the cell in front held something else (act_lanes(), second look)
+    EV_TRY_FWD = 4096u, EV_TRY_DROP = 8192u, EV_UNSTABLE = 16384u,
 };
 
-// bit of an environment's word in the LDS `flag` array: act_lanes() has finished the whole step
-constexpr uint32_t ACT_FINISHED = 1u << 25;
+// An environment's word in the LDS `flag` array between act_lanes() and act_env*(): bits 16-23 number
+// of cells written so far, and
+constexpr uint32_t ACT_REPLAY = 1u << 8;     // some agents are left to act, in order; `tout` marks them
+constexpr uint32_t ACT_REPLAY_ALL = 1u << 9; // act_lanes() did not run: every agent is left to act
+constexpr uint32_t ACT_RESYNC = 1u << 24;    // a blue-door toggle re-synced cell and object
+constexpr uint32_t ACT_FINISHED = 1u << 25;  // act_lanes() has finished the whole step
 
 struct ActEval {
     uint2 r;        // the agent's row after the action
@@ -277,7 +283,8 @@ __device__ __forceinline__ ActEval eval_action(const KParams &p, uint2 r0, uint3
                        : pack_cell(T_DOOR, c, (unlock || so != S_OPEN) ? S_OPEN : S_CLOSED);
     e.bits = (alive ? EV_ALIVE : 0u) | (on_cell ? EV_ONCELL : 0u) | (fwd ? EV_FWD : 0u) | (drop ? EV_DROP : 0u) |
              (pk ? EV_PK : 0u) | (unlock ? EV_UNLOCK : 0u) | (flip ? EV_FLIP : 0u) | (box ? EV_BOX : 0u) |
-             (blue ? EV_BLUE : 0u);
+             (blue ? EV_BLUE : 0u) | ((on_cell && act == ACT_FORWARD) ? EV_TRY_FWD : 0u) |
+             ((on_cell && act == ACT_DROP) ? EV_TRY_DROP : 0u);
     return e;
 }
 
@@ -397,8 +404,9 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
 
     // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
     const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
-    if ((fl0 >> 8) & 1) {
-        // the agents' actions touch each other: replay them one by one in the order of base.py:457-464
+    if (fl0 & (ACT_REPLAY | ACT_REPLAY_ALL)) {
+        // some agents' actions touch each other: those act one by one in the order of base.py:457-464
+        // (`tout` marks them; the others have acted in act_lanes() already)
         if (p.order == nullptr) {
             const uint32_t key = order_key(p, env, h0.y, step);
             for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
@@ -411,11 +419,17 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
             }
         }
 
-        for (int k = 0; k < A; ++k) ev.rewm[k] = 0;  // base.py:454
+        const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
+        if (everyone)
+            for (int k = 0; k < A; ++k) ev.rewm[k] = 0;  // base.py:454
+        else
+            ev.nlog = (fl0 >> 16) & 0xFF;
+        if (fl0 & ACT_RESYNC) ev.flags &= ~FLAG_STALE;
 
         for (int n = 0; n < A; ++n) {  // base.py:464
             const int i = ordb[n];
             if (i >= A) continue;
+            if (!everyone && ev.tout[i] == 0) continue;
             uint8_t *a = ev.rows + 8 * i;
             uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
             const uint32_t w0 = ev.fcv[i];
@@ -493,13 +507,13 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     } else {
         // independent actions: act_lanes() has applied them already
         ev.nlog = (fl0 >> 16) & 0xFF;
-        if ((fl0 >> 24) & 1) ev.flags &= ~FLAG_STALE;
-        if (p.joint()) {  // base.py:558-559
-            bool any = false;
-            for (int k = 0; k < A; ++k) any |= ev.rewm[k] != 0;
-            if (any)
-                for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
-        }
+        if (fl0 & ACT_RESYNC) ev.flags &= ~FLAG_STALE;
+    }
+    if (p.joint()) {  // base.py:558-559: a reward paid to one is paid to all
+        bool any = false;
+        for (int k = 0; k < A; ++k) any |= ev.rewm[k] != 0;
+        if (any)
+            for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
     }
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
@@ -640,8 +654,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     int nlog = (fl0 >> 16) & 0xFF;
     uint64_t termw, rewmw;  // byte k: agent k terminated / reward multiplier
 
-    if ((fl0 >> 8) & 1) {
-        // the agents' actions touch each other: replay them one by one in the order of base.py:457-464
+    if (fl0 & (ACT_REPLAY | ACT_REPLAY_ALL)) {
+        // some agents' actions touch each other: those act one by one in the order of base.py:457-464
+        // (`tout` marks them; the others have acted in act_lanes() already)
         if (p.order == nullptr) {  // see order_key()
             const uint32_t key = order_key(p, env, h0.y, step);
             ordw = 0x0706050403020100ull;
@@ -653,14 +668,17 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                 ordw ^= (d << (8 * k)) ^ (d << (8 * j));
             }
         }
+        const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
+        const uint64_t setw = everyone ? ones : load_bytes(lds + p.o.tout + slot * A, A);  // byte k: agent k acts here
         termw = 0;
-        rewmw = 0;
-        nlog = 0;
+        rewmw = everyone ? 0ull : load_bytes(lds + p.o.rewm + slot * A, A);  // base.py:454
+        if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
 #pragma unroll 1
         for (int k = 0; k < A; ++k) termw |= static_cast<uint64_t>(rows[8 * k + R_TERM]) << (8 * k);
 #pragma unroll 1
         for (int n = 0; n < A; ++n) {  // base.py:464
             const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
+            if (byte_of(setw, i) == 0) continue;
             uint8_t *a = rows + 8 * i;
             const uint2 r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
             uint32_t w = fcv[i];
@@ -686,9 +704,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         // independent actions: act_lanes() has applied them already
         termw = load_bytes(lds + p.o.oterm + slot * A, A);
         rewmw = load_bytes(lds + p.o.rewm + slot * A, A);
-        if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559
-        if ((fl0 >> 24) & 1) flags &= ~FLAG_STALE;
+        if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
     }
+    if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559: a reward paid to one is paid to all
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
     store_bytes(lds + p.o.oterm + slot * A, termw, A);
@@ -804,12 +822,13 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 //
 // Agents of one environment rarely get in each other's way within a single step.  Every lane works
 // out its agent's action against the state at the start of the step and publishes what the others
-// need to know; a second look decides whether any agent of the environment could meet a different
-// world when the actions are taken one by one: a cell in front of it that someone else may write,
-// or - where it matters whether the cell in front is occupied - an agent about to walk into or out
-// of that cell.  Such environments are left untouched for the replay in act_env*(); for the others
-// the result is final here, whatever the order.  Runs on the NE environments from `s0`; the scratch
-// array lives in the image staging area, which is idle during the act phase.
+// need to know; a second look finds the pairs of agents for which the order of acting could matter:
+// a cell in front of one that the other may write, or - where it matters whether the cell in front is
+// occupied - an agent about to walk into or out of that cell.  Both agents of such a pair are left
+// untouched for the in-order replay in act_env*() (`tout` marks them); for all others the result is
+// final here, whatever the order, and neither depends on nor affects what the marked agents do.
+// Runs on the NE environments from `s0`; the scratch array lives in the image staging area, which is
+// idle during the act phase.
 __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int env0, int s0, int ns, int lane,
                                           int my_slot, int my_agent) {
     const int A = p.A();
@@ -828,30 +847,59 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         ev = eval_action(p, r0, w0, lds[p.o.act + s0 * A + lane], hm.x & 0xFF, hm.y >> 16);
     }
     const bool need_occ = mine && needs_occupancy(p, ev);
-    bool occupied = false, clash = false;
+    bool occupied = false, clash = false, unstable = false;
     // when nobody may write a cell and nobody asks where the others stand (the usual case in open
     // rooms that allow overlap) there is nothing to compare
     if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
-    if (mine) pair[lane] = make_uint2((r0.x & 0xFFFFu) | (ev.fxy << 16), ev.bits);
-    wave_sync();
-    if (mine) {
-        const uint2 *q = pair + my_slot * A;
-#pragma unroll 2
-        for (int k = 0; k < A; ++k) {
-            const uint2 o = q[k];
-            const bool at_front = (o.x & 0xFFFFu) == ev.fxy, same_front = (o.x >> 16) == ev.fxy;
-            occupied |= at_front;  // base.py:485,512: every agent counts, terminated ones included
-            if (k != my_agent) {
-                clash |= (ev.bits & EV_ONCELL) && same_front && (o.y & EV_MAY_WRITE);
-                clash |= need_occ && (o.y & EV_FWD) && (at_front || same_front);
+        if (mine) pair[lane] = make_uint2((r0.x & 0xFFFFu) | (ev.fxy << 16), ev.bits);
+        wave_sync();
+        if (mine) {
+            const uint2 *q = pair + my_slot * A;
+            const uint32_t occ_bits = EV_DROP | (p.overlap() ? 0u : EV_FWD);  // actions that ask who stands in front
+#pragma unroll 4
+            for (int k = 0; k < A; ++k) {
+                const uint2 o = q[k];
+                const bool at_front = (o.x & 0xFFFFu) == ev.fxy;               // k stands on the cell in front of me
+                const bool same_front = (o.x >> 16) == ev.fxy;                 // k faces the cell I face
+                const bool at_its_front = (o.x >> 16) == (r0.x & 0xFFFFu);     // I stand on the cell in front of k
+                occupied |= at_front;  // base.py:485,512: every agent counts, terminated ones included
+                if (k != my_agent) {
+                    // my result depends on when k acts ...
+                    unstable |= (ev.bits & EV_ONCELL) && same_front && (o.y & EV_MAY_WRITE);
+                    clash |= need_occ && (o.y & EV_FWD) && (at_front || same_front);
+                    // ... or k's result on when I act
+                    clash |= (o.y & EV_ONCELL) && same_front && (ev.bits & EV_MAY_WRITE);
+                    clash |= (o.y & occ_bits) && (ev.bits & EV_FWD) && (at_its_front || same_front);
+                }
+            }
+            clash |= unstable;
+        }
+        // An agent facing a cell that somebody else may write can end up doing something else than it
+        // would at the start of the step (walk through a door just opened, fail to pick up what is gone):
+        // towards such agents the others go by what the action could do at all, not by what it would do now.
+        if (__ballot(unstable) != 0) {
+            wave_sync();
+            if (unstable) pair[lane].y = ev.bits | EV_UNSTABLE;
+            wave_sync();
+            if (mine) {
+                const uint2 *q = pair + my_slot * A;
+                const uint32_t try_occ = EV_TRY_DROP | (p.overlap() ? 0u : EV_TRY_FWD);
+#pragma unroll 4
+                for (int k = 0; k < A; ++k) {
+                    const uint2 o = q[k];
+                    if (k == my_agent || !(o.y & EV_UNSTABLE)) continue;
+                    const bool at_front = (o.x & 0xFFFFu) == ev.fxy, same_front = (o.x >> 16) == ev.fxy;
+                    const bool at_its_front = (o.x >> 16) == (r0.x & 0xFFFFu);
+                    clash |= need_occ && (o.y & EV_TRY_FWD) && (at_front || same_front);
+                    clash |= (o.y & try_occ) && (ev.bits & EV_FWD) && (at_its_front || same_front);
+                }
             }
         }
     }
-    }
     const uint64_t group = (A == 64 ? ~0ull : ((1ull << A) - 1ull)) << (my_slot * A);
-    const bool replay = (__ballot(clash) & group) != 0;
+    const bool replay = (__ballot(clash) & group) != 0;  // some agents of my environment act later, in order
     finish_action(p, ev, r0, occupied);
-    const bool final_here = mine && !replay;
+    const bool final_here = mine && !clash;
     const bool wr = final_here && (ev.bits & EV_WRITE);
     const uint64_t writers = __ballot(wr) & group;
     const uint64_t resync = __ballot(final_here && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE)) & group;
@@ -862,19 +910,26 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                 ev.ci | (ev.nv << 16);
         lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>((r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u));
         lds[p.o.rewm + s0 * A + lane] = (ev.bits & EV_GOAL) ? 1 : 0;  // base.py:558-562
+    } else if (mine) {
+        lds[p.o.rewm + s0 * A + lane] = 0;  // base.py:454
     }
+    if (mine && replay) lds[p.o.tout + s0 * A + lane] = clash ? 1 : 0;  // who is left to act
+    const uint32_t word = (replay ? ACT_REPLAY : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) |
+                          (resync ? ACT_RESYNC : 0u);
     if (p.kind() == MG_KIND_EMPTY) {
-        // No environment hook: the rest of the step (multigrid/base.py:395-402 plus the bookkeeping of
-        // act_env*()) is done here, the environment's lanes agreeing through ballots.
+        // No environment hook: where no agent is left to act, the rest of the step
+        // (multigrid/base.py:395-402 plus the bookkeeping of act_env*()) is done here, the
+        // environment's lanes agreeing through ballots.
+        const bool done = mine && !replay;
         const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | meta
         const int step = static_cast<int>(h0.x) + 1;           // base.py:395
         const uint32_t my_term = (r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u);
-        const uint64_t goals = __ballot(final_here && (ev.bits & EV_GOAL)) & group;
-        const bool all_term = (__ballot(final_here && my_term != 0) & group) == group;
+        const uint64_t goals = __ballot(done && (ev.bits & EV_GOAL)) & group;
+        const bool all_term = (__ballot(done && my_term != 0) & group) == group;
         const bool trunc = step >= p.max_steps;  // base.py:401-402
         const bool over = trunc || all_term;
         const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
-        if (final_here) {
+        if (done) {
             lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_term);  // base.py:400
             if (p.joint()) lds[p.o.rewm + s0 * A + lane] = goals ? 1 : 0;   // base.py:558-559
             // a cell changed by this step goes back to HBM unless the whole grid is about to be replaced
@@ -903,11 +958,10 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                               static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
             }
         } else if (mine && my_agent == 0) {
-            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = 0x100u;  // replay in act_env*()
+            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = word;
         }
     } else if (mine && my_agent == 0) {  // picked up by act_env*()
-        *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) =
-            (replay ? 0x100u : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) | (resync ? 1u << 24 : 0u);
+        *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = word;
     }
     wave_sync();
 }
@@ -1311,7 +1365,7 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
 #pragma unroll 1
             for (int s0 = 0; s0 < net; s0 += NE) act_lanes(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
         } else if (lane < net) {
-            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = 0x100u;  // replay every environment in order
+            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = ACT_REPLAY_ALL;  // every agent acts in order
         }
         wave_sync();
 #ifdef MGRID_EXPERIMENT

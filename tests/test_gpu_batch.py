@@ -331,3 +331,32 @@ def test_explicit_tile_shapes(case, tile, monkeypatch):
             ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
     compare_state(env, ora, f"{case} tile {tile} final")
     env.close()
+
+
+@pytest.mark.parametrize("case", ["crowd16_lh", "crowd8_rbd", "crowd8_bup", "crowd12_bup", "cfg5_nooverlap", "crowd8_empty"])
+def test_crowded_rooms_at_scale(case):
+    """Many environments in which agents block each other, reach for the same objects and walk through doors
+    that others open in the same step: the cases in which only some agents of an environment are replayed in order."""
+    table = dict(CASES, crowd12_bup=("MultiGrid-BlockedUnlockPickup-v0", 12, dict(max_steps=60, allow_agent_overlap=False)))
+    e = 20000
+    spec, pool, env, ora = make(case, e, table=table, n_layouts=128, autoreset=2)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(9)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    env.reset()
+    idx = expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    for t in range(45):
+        actions, order = rand_inputs(rng, e, a)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        compare(out, res, f"{case} step {t}", image=(t % 5 == 4))
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+    compare_state(env, ora, f"{case} final")
+    env.close()

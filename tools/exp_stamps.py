@@ -9,8 +9,8 @@ from multigrid_amd.batched import BatchedMultiGrid
 NAMES = {1: "hdr->LDS", 2: "act", 3: "resets+scalars", 4: "pass0: grid->LDS", 5: "pass0: patch+front cells", 6: "pass0: overlay",
          7: "pass0: observe", 8: "pass0: copy-out", 9: "remaining passes", 10: "hdr->HBM"}
 
-def run(cfg, agents, e):
-    spec, gen = envs.make_spec(cfg, num_agents=agents)
+def run(cfg, agents, e, **kw):
+    spec, gen = envs.make_spec(cfg, num_agents=agents, **kw)
     env = BatchedMultiGrid(spec, e, device=0, autoreset=1, seed=1)
     pool = layouts.make_pool(gen, 256)
     env.upload_layouts(*pool[:3]); env.reset()
@@ -39,6 +39,7 @@ def run(cfg, agents, e):
     env.close()
 
 if __name__ == "__main__":
-    cases = (("MultiGrid-Empty-16x16-v0", 8, 131072), ("MultiGrid-BlockedUnlockPickup-v0", 2, 65536), ("MultiGrid-LockedHallway-4Rooms-v0", 4, 65536), ("MultiGrid-RedBlueDoors-8x8-v0", 2, 4096))
+    cases = (("MultiGrid-Empty-16x16-v0", 8, 131072), ("MultiGrid-BlockedUnlockPickup-v0", 2, 65536), ("MultiGrid-LockedHallway-4Rooms-v0", 4, 65536), ("MultiGrid-RedBlueDoors-8x8-v0", 2, 4096),
+             ("MultiGrid-Empty-16x16-v0", 8, 131072, dict(allow_agent_overlap=False)))
     for i in [int(x) for x in os.environ.get("CASES", "0").split(",")]:
-        run(*cases[i])
+        run(*cases[i][:3], **(cases[i][3] if len(cases[i]) > 3 else {}))
