@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 2
+#define MG_ABI_VERSION 3
 
 /* error codes */
 #define MG_OK 0
@@ -102,6 +102,27 @@ const char *mg_last_error(MgHandle h);
  * locked_hallway.py:146).  HOST pointers; copied, synchronous. */
 int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, const uint8_t *meta,
                       int32_t n);
+
+/* Parameters of the `_gen_grid` procedures that MgConfig does not carry. */
+typedef struct MgLayoutSpec {
+    int32_t size;              /* Empty, RedBlueDoors: `size` (empty.py:112, redbluedoors.py:103);
+                                  BlockedUnlockPickup, LockedHallway: `room_size` (blockedunlockpickup.py:105,
+                                  locked_hallway.py:100) */
+    int32_t random_start;      /* Empty: agent_start_pos is None, agents placed at random (empty.py:166-171) */
+    int32_t start_x, start_y, start_dir; /* Empty: the fixed start otherwise (empty.py:113-114) */
+    int32_t max_hallway_keys;  /* LockedHallway (locked_hallway.py:101) */
+    int32_t max_keys_per_room; /* LockedHallway (locked_hallway.py:102) */
+    uint8_t agent_color[64];   /* colour index of agent k = its team's colour (base.py:185-203) */
+} MgLayoutSpec;
+
+/* Replaces the host loop "reset() N times, then mg_upload_layouts": draws `n` start states on the
+ * device with the environment class's own `_gen_grid` procedure (multigrid/envs/empty.py:152,
+ * redbluedoors.py:141, blockedunlockpickup.py:136, locked_hallway.py:146; place_obj / place_agent
+ * multigrid/base.py:661-749) and makes them the handle's layout pool.  Layout l depends only on
+ * (seed, l).  The random numbers are a counter generator's, not numpy's: the layouts follow the
+ * reference's distribution, not its sequences.  Synchronous; MG_EINVAL when the spec does not match the
+ * handle's grid or a room cannot hold what has to be placed in it. */
+int mg_generate_layouts(MgHandle h, const MgLayoutSpec *spec, int32_t n, uint64_t seed);
 
 /* Replaces MultiGridEnv.reset (multigrid/base.py:310-362).  `layout_idx_dev` int32[E] picks the
  * start state per environment (NULL: environment e takes layout (env_id_offset + e +

@@ -19,10 +19,10 @@ MG_OK = 0
 KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
-EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts",
+EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
            "mg_reset", "mg_step", "mg_step_n", "mg_gen_obs", "mg_get_state", "mg_set_state", "mg_stats")
 
 
@@ -36,6 +36,12 @@ class MgConfig(ctypes.Structure):
 class MgOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev", "onehot_dev")]
+
+
+class MgLayoutSpec(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "size", "random_start", "start_x", "start_y", "start_dir", "max_hallway_keys",
+        "max_keys_per_room")] + [("agent_color", ctypes.c_uint8 * 64)]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -71,6 +77,7 @@ def lib() -> ctypes.CDLL:
         L.mg_last_error.argtypes = [vp]
         L.mg_last_error.restype = ctypes.c_char_p
         L.mg_upload_layouts.argtypes = [vp, vp, vp, vp, i32]
+        L.mg_generate_layouts.argtypes = [vp, ctypes.POINTER(MgLayoutSpec), i32, ctypes.c_uint64]
         L.mg_reset.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step_n.argtypes = [vp, i32, vp, vp, ctypes.POINTER(MgOut), vp]

@@ -111,6 +111,25 @@ class BatchedMultiGrid:
                                            meta.ctypes.data, n), self._h)
         self.num_layouts = n
 
+    def generate_layouts(self, gen, n: int, seed: int = 0):
+        """Draw ``n`` start states on the device with the environment class's own ``_gen_grid`` procedure
+        (``mg_generate_layouts``) instead of uploading host-generated ones.  ``gen`` is the layout generator
+        returned by ``envs.make_spec`` (a ``functools.partial`` whose keywords carry the family's parameters)."""
+        kw = dict(getattr(gen, "keywords", {}) or {})
+        ls = _lib.MgLayoutSpec()
+        ls.size = int(kw.get("size", kw.get("room_size", 0)))
+        start = kw.get("agent_start_pos", (1, 1))
+        sdir = kw.get("agent_start_dir", 0)
+        ls.random_start = int(start is None or sdir is None)
+        if not ls.random_start:
+            ls.start_x, ls.start_y, ls.start_dir = int(start[0]), int(start[1]), int(sdir)
+        ls.max_hallway_keys = int(kw.get("max_hallway_keys", 1))
+        ls.max_keys_per_room = int(kw.get("max_keys_per_room", 2))
+        for k, c in enumerate(kw["agent_colors"]):
+            ls.agent_color[k] = int(c)
+        check(_lib.lib().mg_generate_layouts(self._h, ctypes.byref(ls), int(n), int(seed) & (2 ** 64 - 1)), self._h)
+        self.num_layouts = int(n)
+
     def reset(self, layout_idx=None, mask=None, out: Optional[StepOutput] = None) -> StepOutput:
         """``MultiGridEnv.reset`` (multigrid/base.py:310) for all (or the masked) environments."""
         li = None

@@ -1760,6 +1760,219 @@ __global__ void mg_stats_kernel(const int64_t *shards, int64_t *out, int64_t lau
     out[k] = s;
 }
 
+// ---- start states generated on the device ----------------------------------------------------------------
+//
+// The `_gen_grid` procedures of the four environment classes (multigrid/envs/empty.py:152-171,
+// redbluedoors.py:141-168, blockedunlockpickup.py:136-158, locked_hallway.py:146-184) with their helpers
+// (Grid.wall_rect grid.py:168-186, MultiGridEnv.place_obj / place_agent base.py:661-749, RoomGrid
+// roomgrid.py:197-391), one thread per layout, written straight into the pool formats.  The draws come
+// from a counter generator (splitmix64 keyed by seed and layout index) instead of numpy's PCG64, so the
+// layouts follow the reference's distribution without repeating its sequences; a rejection loop that
+// does not end within LAYOUT_MAX_TRIES draws (a room too full for its agents) reports failure.
+
+constexpr int LAYOUT_MAX_TRIES = 20000;
+
+struct LayoutGen {
+    const KParams &p;
+    const MgLayoutSpec &ls;
+    uint16_t *g;   // the layout's grid in the pool
+    uint8_t *rows; // its agent rows (inside the header block)
+    uint64_t state;
+    bool failed;
+
+    __device__ uint32_t next() {
+        state += 0x9E3779B97F4A7C15ull;
+        return static_cast<uint32_t>(mix64(state) >> 32);
+    }
+    // RandomMixin._rand_int(lo, hi): uniform on lo .. hi - 1, multigrid/utils/random.py:22-31
+    __device__ int rand_int(int lo, int hi) { return lo + static_cast<int>(__umulhi(next(), static_cast<uint32_t>(hi - lo))); }
+    __device__ uint32_t cell(int x, int y) const { return g[x * p.H() + y]; }
+    __device__ void set(int x, int y, uint32_t t, uint32_t c, uint32_t st) { g[x * p.H() + y] = static_cast<uint16_t>(pack_cell(t, c, st)); }
+    __device__ void wall_rect(int x, int y, int w, int h) {
+        for (int i = 0; i < w; ++i) { set(x + i, y, T_WALL, 5, 0); set(x + i, y + h - 1, T_WALL, 5, 0); }
+        for (int j = 0; j < h; ++j) { set(x, y + j, T_WALL, 5, 0); set(x + w - 1, y + j, T_WALL, 5, 0); }
+    }
+    __device__ bool agent_at(int x, int y) const {
+        bool hit = false;
+        for (int k = 0; k < p.A(); ++k) hit |= rows[8 * k + R_X] == x && rows[8 * k + R_Y] == y;
+        return hit;
+    }
+    // MultiGridEnv.place_obj, base.py:661-728; `near` is reject_next_to of roomgrid.py:44-49.  An agent
+    // that has not been placed yet sits at (255, 255) or, in room grids, at the default position.
+    __device__ void place(int tx, int ty, int sw, int sh, bool near, int &ox, int &oy) {
+        tx = max(tx, 0);
+        ty = max(ty, 0);
+        const int hx = min(tx + sw, p.W()), hy = min(ty + sh, p.H());
+        for (int tries = 0; tries < LAYOUT_MAX_TRIES; ++tries) {
+            const int x = rand_int(tx, hx), y = rand_int(ty, hy);
+            if ((cell(x, y) & 15) != T_EMPTY) continue;
+            if (agent_at(x, y)) continue;
+            if (near) {
+                bool close = false;
+                for (int k = 0; k < p.A(); ++k) {
+                    const int dx = x - rows[8 * k + R_X], dy = y - rows[8 * k + R_Y];
+                    close |= dx * dx + dy * dy <= 1;
+                }
+                if (close) continue;
+            }
+            ox = x;
+            oy = y;
+            return;
+        }
+        failed = true;
+        ox = tx;
+        oy = ty;
+    }
+    // MultiGridEnv.place_agent, base.py:738-749
+    __device__ void place_agent(int k, int tx, int ty, int sw, int sh) {
+        rows[8 * k + R_X] = 255;
+        rows[8 * k + R_Y] = 255;
+        int x, y;
+        place(tx, ty, sw, sh, false, x, y);
+        rows[8 * k + R_X] = static_cast<uint8_t>(x);
+        rows[8 * k + R_Y] = static_cast<uint8_t>(y);
+        rows[8 * k + R_DIR] = static_cast<uint8_t>(rand_int(0, 4));
+    }
+    // RoomGrid._gen_grid, roomgrid.py:197-230: the rooms' walls, every agent at the default position
+    __device__ void rooms(int rs, int nrows, int ncols) {
+        for (int r = 0; r < nrows; ++r)
+            for (int c = 0; c < ncols; ++c) wall_rect(c * (rs - 1), r * (rs - 1), rs, rs);
+        for (int k = 0; k < p.A(); ++k) {
+            rows[8 * k + R_X] = static_cast<uint8_t>((ncols / 2) * (rs - 1) + rs / 2);
+            rows[8 * k + R_Y] = static_cast<uint8_t>((nrows / 2) * (rs - 1) + rs / 2);
+            rows[8 * k + R_DIR] = 0;
+        }
+    }
+    // RandomMixin._rand_perm, random.py:72-80 (Fisher-Yates)
+    __device__ void shuffle(uint8_t *v, int n) {
+        for (int i = n - 1; i > 0; --i) {
+            const int j = rand_int(0, i + 1);
+            const uint8_t t = v[i];
+            v[i] = v[j];
+            v[j] = t;
+        }
+    }
+};
+
+__global__ void mg_generate_layouts_kernel(KParams p, MgLayoutSpec ls, uint8_t *pool_hdr, uint8_t *pool_grid, int n,
+                                           uint64_t seed, int *failures) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n) return;
+    const int W = p.W(), H = p.H(), A = p.A();
+    uint8_t *hd = pool_hdr + static_cast<size_t>(l) * p.HS;
+    LayoutGen G{p, ls, reinterpret_cast<uint16_t *>(pool_grid + static_cast<size_t>(l) * p.GS), hd + H_ROWS,
+                mix64(seed ^ mix64(static_cast<uint64_t>(l) + 0x632BE59BD9B4E019ull)), false};
+    for (int i = 0; i < p.HS; ++i) hd[i] = 0;
+    for (int i = 0; i < p.GS / 2; ++i) G.g[i] = 0;
+    for (int i = 0; i < W * H; ++i) G.g[i] = CELL_EMPTY;  // Grid.__init__, grid.py:53-54
+    for (int k = 0; k < A; ++k) {
+        uint8_t *r = G.rows + 8 * k;
+        r[R_X] = r[R_Y] = 255;  // not placed yet (Agent.reset, agent.py:172-173)
+        r[R_CT] = T_EMPTY;       // carrying nothing
+        r[R_COLOR] = ls.agent_color[k];
+    }
+    uint32_t meta = 0;
+    const int kind = p.kind();
+    if (kind == MG_KIND_EMPTY) {  // empty.py:152-171
+        G.wall_rect(0, 0, W, H);
+        G.set(W - 2, H - 2, T_GOAL, 1, 0);
+        for (int k = 0; k < A; ++k) {
+            if (ls.random_start) {
+                G.place_agent(k, 0, 0, W, H);
+            } else {
+                G.rows[8 * k + R_X] = static_cast<uint8_t>(ls.start_x);
+                G.rows[8 * k + R_Y] = static_cast<uint8_t>(ls.start_y);
+                G.rows[8 * k + R_DIR] = static_cast<uint8_t>(ls.start_dir);
+            }
+        }
+    } else if (kind == MG_KIND_REDBLUEDOORS) {  // redbluedoors.py:141-168
+        const int rx0 = W / 4, rw = W / 2;
+        G.wall_rect(0, 0, W, H);
+        G.wall_rect(rx0, 0, rw, H);
+        for (int k = 0; k < A; ++k) G.place_agent(k, rx0, 0, rw, H);
+        const int ry = G.rand_int(1, H - 1);
+        G.set(rx0, ry, T_DOOR, 0, S_LOCKED);
+        const int bx = rx0 + rw - 1, by = G.rand_int(1, H - 1);
+        G.set(bx, by, T_DOOR, 2, S_LOCKED);
+        meta = static_cast<uint32_t>(rx0) | (ry << 8) | (bx << 16) | (by << 24);
+    } else if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:136-158
+        const int rs = ls.size;
+        G.rooms(rs, 1, 2);
+        int x, y;
+        const int box_color = G.rand_int(0, 6);
+        G.place(rs - 1, 0, rs, rs, true, x, y);  // the box, in the right room (roomgrid.py:232-270)
+        G.set(x, y, T_BOX, box_color, 0);
+        const int door_color = G.rand_int(0, 6);
+        const int dx = rs - 1, dy = G.rand_int(1, rs - 1);  // Room.set_door_pos, roomgrid.py:86-127
+        G.set(dx, dy, T_DOOR, door_color, S_LOCKED);
+        G.set(dx - 1, dy, T_BALL, G.rand_int(0, 6), 0);     // the ball in front of the door (:149)
+        G.place(0, 0, rs, rs, true, x, y);                  // the door's key, in the left room
+        G.set(x, y, T_KEY, door_color, 0);
+        for (int k = 0; k < A; ++k) {  // RoomGrid.place_agent, roomgrid.py:363-391
+            for (int tries = 0; tries < LAYOUT_MAX_TRIES; ++tries) {
+                G.place_agent(k, 0, 0, rs, rs);
+                const uint8_t *r = G.rows + 8 * k;
+                const uint32_t t = G.cell(r[R_X] + dir_dx(r[R_DIR]), r[R_Y] + dir_dy(r[R_DIR])) & 15;
+                if (t == T_EMPTY || t == T_WALL || G.failed) break;
+                if (tries == LAYOUT_MAX_TRIES - 1) G.failed = true;
+            }
+        }
+    } else {  // locked_hallway.py:146-184
+        const int rs = ls.size, nrooms = p.num_rooms(), nrows = nrooms / 2;
+        G.rooms(rs, nrows, 3);
+        uint8_t seq[12], doors[6];
+        const int reps = (nrooms + 5) / 6;
+        for (int i = 0; i < 6 * reps; ++i) seq[i] = static_cast<uint8_t>(i % 6);
+        G.shuffle(seq, 6 * reps);
+        for (int r = 0; r < nrows - 1; ++r)  // the hallway is one room: remove_wall(down), roomgrid.py:347-349
+            for (int i = 1; i < rs - 1; ++i) G.set((rs - 1) + i, r * (rs - 1) + rs - 1, T_EMPTY, 0, 0);
+        for (int i = 0; i < nrooms; ++i) doors[i] = seq[i];
+        G.shuffle(doors, nrooms);
+        uint8_t room_col[6], room_row[6];
+        int left = nrooms;
+        for (int r = 0; r < nrows; ++r)
+            for (int side = 0; side < 2; ++side) {
+                const int color = doors[--left];
+                const int col = side == 0 ? 0 : 2;
+                room_col[color] = static_cast<uint8_t>(col);
+                room_row[color] = static_cast<uint8_t>(r);
+                const int top = r * (rs - 1), lft = col * (rs - 1);
+                G.set(side == 0 ? lft + rs - 1 : lft, (top + top + rs - 1) / 2, T_DOOR, color, S_LOCKED);
+            }
+        const int hall_keys = G.rand_int(1, ls.max_hallway_keys + 1);
+        int x, y;
+        for (int i = 0; i < min(hall_keys, nrooms); ++i) {
+            G.place(rs - 1, 0, rs, H, false, x, y);
+            G.set(x, y, T_KEY, seq[i], 4);  // Key() is "available", world_object.py:519-521
+        }
+        int key_index = hall_keys;
+        while (key_index < nrooms) {
+            const int c = seq[key_index - 1];
+            const int room_keys = G.rand_int(1, ls.max_keys_per_room + 1);
+            const int stop = min(key_index + room_keys, nrooms);
+            for (int i = key_index; i < stop; ++i) {
+                G.place(room_col[c] * (rs - 1), room_row[c] * (rs - 1), rs, rs, false, x, y);
+                G.set(x, y, T_KEY, seq[i], 4);
+            }
+            key_index = stop;
+        }
+        for (int k = 0; k < A; ++k) G.place_agent(k, rs - 1, 0, rs, H);
+    }
+    // header block: door positions and the cells in front of the agents (kept current by the step kernel)
+    *reinterpret_cast<uint32_t *>(hd + H_META) = meta;
+    uint16_t *fc = reinterpret_cast<uint16_t *>(hd + p.HFC);
+    for (int k = 0; k < A; ++k) {
+        const uint32_t ci = G.rows[8 * k + R_X] < W ? front_index(p, *reinterpret_cast<const uint32_t *>(G.rows + 8 * k)) : FC_NONE;
+        fc[k] = ci == FC_NONE ? static_cast<uint16_t>(0) : G.g[ci];
+        if (G.rows[8 * k + R_X] >= W || G.rows[8 * k + R_Y] >= H) G.failed = true;
+    }
+    if (kind == MG_KIND_REDBLUEDOORS) {
+        fc[A] = G.g[(meta & 0xFF) * H + ((meta >> 8) & 0xFF)];
+        fc[A + 1] = G.g[((meta >> 16) & 0xFF) * H + (meta >> 24)];
+    }
+    if (G.failed) atomicAdd(failures, 1);
+}
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -2054,6 +2267,63 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
     h->kp.num_layouts = n;
     h->pool_walled = walled;
     if (!walled) h->kp.bits &= ~(1u << 20);
+    return MG_OK;
+}
+
+int mg_generate_layouts(MgHandle h, const MgLayoutSpec *spec, int32_t n, uint64_t seed) {
+    if (!h) return MG_EINVAL;
+    if (!spec || n < 1) return fail(h, MG_EINVAL, "mg_generate_layouts: null spec or n < 1");
+    const KParams &kp = h->kp;
+    const int W = kp.W(), H = kp.H(), kind = kp.kind();
+    // the grid size must be the one the family builds
+    bool ok = true;
+    if (kind == MG_KIND_EMPTY) {
+        ok = spec->size == W && W == H &&
+             (spec->random_start || (spec->start_x >= 0 && spec->start_x < W && spec->start_y >= 0 && spec->start_y < H &&
+                                     spec->start_dir >= 0 && spec->start_dir < 4));
+    } else if (kind == MG_KIND_REDBLUEDOORS) {
+        ok = W == 2 * spec->size && H == spec->size && spec->size >= 4;
+    } else if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
+        ok = spec->size >= 4 && W == 2 * (spec->size - 1) + 1 && H == spec->size;
+    } else {
+        ok = spec->size >= 4 && kp.num_rooms() >= 2 && kp.num_rooms() % 2 == 0 && W == 3 * (spec->size - 1) + 1 &&
+             H == (kp.num_rooms() / 2) * (spec->size - 1) + 1 && spec->max_hallway_keys >= 1 && spec->max_keys_per_room >= 1;
+    }
+    if (!ok) return fail(h, MG_EINVAL, "mg_generate_layouts: spec does not match the %dx%d grid of this handle", W, H);
+    for (int k = 0; k < kp.A(); ++k)
+        if (spec->agent_color[k] > 15) return fail(h, MG_EINVAL, "mg_generate_layouts: agent colour out of range");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    MG_HIP(h, hipDeviceSynchronize());
+    uint8_t *ph = nullptr, *pg = nullptr;
+    int *failures = nullptr;
+    const size_t hb = static_cast<size_t>(n) * kp.HS, gb = static_cast<size_t>(n) * kp.GS;
+    hipError_t e = hipMalloc(&ph, hb);
+    if (e == hipSuccess) e = hipMalloc(&pg, gb);
+    if (e == hipSuccess) e = hipMalloc(&failures, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(failures, 0, sizeof(int));
+    int failed = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mg_generate_layouts_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, kp, *spec, ph, pg, n, seed,
+                           failures);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&failed, failures, sizeof(int), hipMemcpyDeviceToHost);
+    if (failures) (void)hipFree(failures);
+    if (e != hipSuccess || failed) {
+        if (ph) (void)hipFree(ph);
+        if (pg) (void)hipFree(pg);
+        if (e != hipSuccess) return fail(h, MG_EHIP, "mg_generate_layouts: %s", hipGetErrorString(e));
+        return fail(h, MG_EINVAL, "mg_generate_layouts: %d of %d layouts could not be completed (rooms too full?)", failed, n);
+    }
+    if (h->pool_hdr) (void)hipFree(h->pool_hdr);
+    if (h->pool_grid) (void)hipFree(h->pool_grid);
+    h->pool_hdr = ph;
+    h->pool_grid = pg;
+    h->num_layouts = n;
+    h->kp.pool_hdr = ph;
+    h->kp.pool_grid = pg;
+    h->kp.num_layouts = n;
+    h->pool_walled = true;  // every family rings its grid with (2, 5, 0) walls
     return MG_OK;
 }
 

@@ -31,7 +31,9 @@ from .batched import BatchedMultiGrid
 class MultiGridVectorEnv:
     def __init__(self, name: str, num_envs: int, agents: Optional[int] = None, device: int | str = 0,
                  num_layouts: int = 1024, seed: int = 0, one_hot: bool = False, single_agent: bool = False,
-                 numpy: bool = False, env_id_offset: int = 0, **kwargs):
+                 numpy: bool = False, env_id_offset: int = 0, device_layouts: bool = False, **kwargs):
+        """``device_layouts``: draw the pool of start states on the GPU (``mg_generate_layouts``) instead of
+        generating it on the host; large pools then cost milliseconds."""
         self.spec, self._gen = envs.make_spec(name, num_agents=agents, **kwargs)
         self.num_envs = int(num_envs)
         self.num_agents = self.spec["num_agents"]
@@ -41,7 +43,7 @@ class MultiGridVectorEnv:
         self.num_actions = 7  # multigrid/core/actions.py:4-15
         self._sim = BatchedMultiGrid(self.spec, self.num_envs, device=device, autoreset=_lib.AUTORESET_SAME_STEP,
                                      env_id_offset=env_id_offset, seed=seed, one_hot=one_hot)
-        self._num_layouts, self._seed = int(num_layouts), int(seed)
+        self._num_layouts, self._seed, self._device_layouts = int(num_layouts), int(seed), bool(device_layouts)
         self._uploaded = None
         dev = self._sim.device
         self._ret = torch.zeros((self.num_envs, self.num_agents), dtype=torch.float64, device=dev)
@@ -58,8 +60,11 @@ class MultiGridVectorEnv:
 
     def _layouts(self, seed: int):
         if self._uploaded != seed:
-            grids, ags, metas, _ = layouts.make_pool(self._gen, self._num_layouts, seed0=seed)
-            self._sim.upload_layouts(grids, ags, metas)
+            if self._device_layouts:
+                self._sim.generate_layouts(self._gen, self._num_layouts, seed=seed)
+            else:
+                grids, ags, metas, _ = layouts.make_pool(self._gen, self._num_layouts, seed0=seed)
+                self._sim.upload_layouts(grids, ags, metas)
             self._uploaded = seed
 
     # -- SyncVectorEnv surface -----------------------------------------------------------------------

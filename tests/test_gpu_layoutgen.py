@@ -1,0 +1,216 @@
+"""Start states drawn on the device (mg_generate_layouts): structure, determinism, the reference's distribution
+(against the host generators, which are bit-identical to the reference's `_gen_grid`), and use in stepping.
+
+The device generator follows the reference's procedures with a different random number generator, so equality
+with the reference is one of distributions: every statistic below is compared between N device layouts and N
+host layouts with a two-sample chi-square test at fixed seeds (the outcome is deterministic)."""
+import numpy as np
+import pytest
+
+from multigrid_amd import envs, layouts
+from multigrid_amd.constants import BALL, BOX, DOOR, EMPTY, GOAL, KEY, LOCKED, WALL
+
+pytestmark = pytest.mark.gpu
+
+FAMILIES = {
+    "empty_random": ("MultiGrid-Empty-Random-6x6-v0", 3, {}),
+    "empty_fixed": ("MultiGrid-Empty-16x16-v0", 8, {}),
+    "redbluedoors": ("MultiGrid-RedBlueDoors-8x8-v0", 2, {}),
+    "blockedunlockpickup": ("MultiGrid-BlockedUnlockPickup-v0", 2, {}),
+    "lockedhallway4": ("MultiGrid-LockedHallway-4Rooms-v0", 4, {}),
+    "lockedhallway6": ("MultiGrid-LockedHallway-6Rooms-v0", 3, dict(max_hallway_keys=2)),
+}
+
+
+def device_layouts(name, agents, kw, n, seed):
+    from multigrid_amd.batched import BatchedMultiGrid
+    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+    env = BatchedMultiGrid(spec, n, device=0)
+    env.generate_layouts(gen, n, seed=seed)
+    env.reset(layout_idx=np.arange(n))
+    st = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    return spec, gen, env, st
+
+
+def host_layouts(gen, n, seed0=1000):
+    g, a, m, _ = layouts.make_pool(gen, n, seed0=seed0)
+    return dict(grid=g, agents=a, meta=m)
+
+
+def chi2_same(x, y, bins):
+    """Two-sample chi-square on integer samples; returns the p-value."""
+    from scipy.stats import chi2_contingency
+    hx = np.bincount(x, minlength=bins)[:bins]
+    hy = np.bincount(y, minlength=bins)[:bins]
+    keep = (hx + hy) > 0
+    if keep.sum() < 2:
+        assert np.array_equal(hx, hy) or (hx > 0).tolist() == (hy > 0).tolist()
+        return 1.0
+    return chi2_contingency(np.stack([hx[keep], hy[keep]]))[1]
+
+
+def cell_index_of(grid, typ):
+    """Index x * H + y of the (single) cell of a type in each layout; -1 when absent."""
+    n, w, h, _ = grid.shape
+    flat = (grid[..., 0] == typ).reshape(n, -1)
+    return np.where(flat.any(axis=1), flat.argmax(axis=1), -1)
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+def test_structure_and_determinism(family):
+    name, agents, kw = FAMILIES[family]
+    n = 4096
+    spec, gen, env, st = device_layouts(name, agents, kw, n, seed=5)
+    g, a, meta = st["grid"], st["agents"], st["meta"]
+    w, h = spec["width"], spec["height"]
+    # ringed by walls, agents inside on overlappable cells, nothing carried, colours as asked
+    border = np.ones((w, h), bool)
+    border[1:-1, 1:-1] = False
+    assert (g[:, border] == (WALL, 5, 0)).all()
+    assert (a[:, :, 0] < w).all() and (a[:, :, 1] < h).all() and (a[:, :, 2] < 4).all() and (a[:, :, 3] == 0).all()
+    assert (a[:, :, 4:7] == (EMPTY, 0, 0)).all()
+    assert (a[:, :, 7] == np.array(gen.keywords["agent_colors"])).all()
+    under = g[np.arange(n)[:, None], a[:, :, 0], a[:, :, 1], 0]
+    assert (under == EMPTY).all()
+    cnt = lambda t: (g[..., 0] == t).reshape(n, -1).sum(axis=1)
+    if spec["kind"] == 0:
+        assert (cnt(GOAL) == 1).all() and (g[:, w - 2, h - 2] == (GOAL, 1, 0)).all()
+        if family == "empty_fixed":
+            assert (a[:, :, :3] == (1, 1, 0)).all()
+        else:  # placed agents never share a cell (base.py:702-704)
+            pos = a[:, :, 0].astype(int) * h + a[:, :, 1]
+            assert all(len(set(r)) == agents for r in pos[:500])
+    elif spec["kind"] == 1:
+        assert (cnt(DOOR) == 2).all()
+        rx, ry, bx, by = (meta[:, i] for i in range(4))
+        assert (rx == w // 4).all() and (bx == w // 4 + w // 2 - 1).all()
+        assert (g[np.arange(n), rx, ry] == (DOOR, 0, LOCKED)).all() and (g[np.arange(n), bx, by] == (DOOR, 2, LOCKED)).all()
+        assert ((a[:, :, 0] > w // 4) & (a[:, :, 0] < w // 4 + w // 2 - 1)).all()
+    elif spec["kind"] == 2:
+        rs = h
+        assert (cnt(DOOR) == 1).all() and (cnt(BOX) == 1).all() and (cnt(BALL) == 1).all() and (cnt(KEY) == 1).all()
+        d, bx, bl, ky = (cell_index_of(g, t) for t in (DOOR, BOX, BALL, KEY))
+        assert (d // h == rs - 1).all() and (bl == d - h).all()          # ball left of the door
+        assert (bx // h > rs - 1).all() and (ky // h < rs - 1).all()      # box right, key left
+        flatg = g.reshape(n, -1, 3)
+        assert (flatg[np.arange(n), ky, 1] == flatg[np.arange(n), d, 1]).all()  # the key opens the door
+        assert (flatg[np.arange(n), d, 2] == LOCKED).all() and (flatg[np.arange(n), ky, 2] == 0).all()
+        assert (a[:, :, 0] < rs - 1).all()
+        # RoomGrid.place_agent: the cell in front is empty or a wall (roomgrid.py:385-390)
+        dx, dy = np.array([1, 0, -1, 0]), np.array([0, 1, 0, -1])
+        front = g[np.arange(n)[:, None], a[:, :, 0] + dx[a[:, :, 2]], a[:, :, 1] + dy[a[:, :, 2]], 0]
+        assert np.isin(front, (EMPTY, WALL)).all()
+    else:
+        rooms = spec["num_rooms"]
+        assert (cnt(DOOR) == rooms).all() and (cnt(KEY) == rooms).all()
+        for i in range(200):
+            doors = g[i][g[i, :, :, 0] == DOOR]
+            keys = g[i][g[i, :, :, 0] == KEY]
+            assert sorted(doors[:, 1]) == sorted(keys[:, 1]) and len(set(doors[:, 1])) == rooms
+            assert (doors[:, 2] == LOCKED).all() and (keys[:, 2] == 4).all()
+        rs = (w - 1) // 3 + 1
+        assert ((a[:, :, 0] > rs - 1) & (a[:, :, 0] < 2 * (rs - 1))).all()  # agents start in the hallway
+    # layout l depends on (seed, l) only
+    _, _, env2, st2 = device_layouts(name, agents, kw, 512, seed=5)
+    np.testing.assert_array_equal(st2["grid"], g[:512])
+    np.testing.assert_array_equal(st2["agents"], a[:512])
+    _, _, env3, st3 = device_layouts(name, agents, kw, 512, seed=6)
+    if family != "empty_fixed":
+        assert not np.array_equal(st3["grid"], g[:512]) or not np.array_equal(st3["agents"], a[:512])
+    for e in (env, env2, env3):
+        e.close()
+
+
+@pytest.mark.parametrize("family", ["empty_random", "redbluedoors", "blockedunlockpickup", "lockedhallway4", "lockedhallway6"])
+def test_distribution_matches_host_generators(family):
+    import os
+    name, agents, kw = FAMILIES[family]
+    n = int(os.environ.get("MG_LAYOUT_SAMPLES", 3000))
+    spec, gen, env, dev = device_layouts(name, agents, kw, n, seed=11)
+    env.close()
+    host = host_layouts(gen, n)
+    w, h = spec["width"], spec["height"]
+    checks = {}
+    for k in range(agents):
+        for label, src in (("dev", dev), ("host", host)):
+            a = src["agents"]
+            checks.setdefault(f"agent{k} cell", {})[label] = a[:, k, 0].astype(int) * h + a[:, k, 1]
+            checks.setdefault(f"agent{k} dir", {})[label] = a[:, k, 2].astype(int)
+    for label, src in (("dev", dev), ("host", host)):
+        g = src["grid"]
+        flat = g.reshape(len(g), -1, 3)
+        for typ, tname in ((DOOR, "door"), (BOX, "box"), (BALL, "ball"), (KEY, "key")):
+            present = flat[:, :, 0] == typ
+            if not present.any():
+                continue
+            # histogram over (cell, colour) of every object of the type
+            idx = np.nonzero(present)
+            checks.setdefault(f"{tname} cell", {})[label] = idx[1]
+            checks.setdefault(f"{tname} colour", {})[label] = flat[idx[0], idx[1], 1].astype(int)
+            checks.setdefault(f"{tname} cell x colour", {})[label] = idx[1] * 6 + flat[idx[0], idx[1], 1].astype(int)
+        if spec["kind"] == 3:  # how many keys lie in the hallway, and which room holds how many
+            rs = (w - 1) // 3 + 1
+            keyx = [np.nonzero(gi[:, :, 0] == KEY)[0] for gi in g]
+            checks.setdefault("keys in hallway", {})[label] = np.array([int(((x > rs - 1) & (x < 2 * (rs - 1))).sum()) for x in keyx])
+            checks.setdefault("keys in left rooms", {})[label] = np.array([int((x < rs - 1).sum()) for x in keyx])
+    assert len(checks) >= 2 * agents + (0 if spec["kind"] == 0 else 3)
+    worst = (1.0, "")
+    for what, pair in checks.items():
+        bins = int(max(pair["dev"].max(), pair["host"].max())) + 1
+        p = chi2_same(pair["dev"], pair["host"], bins)
+        worst = min(worst, (p, what))
+        assert p > 1e-4, f"{family}: {what} differs from the host generator (p = {p:.2e})"
+    print(f"{family}: {len(checks)} statistics, smallest p = {worst[0]:.3f} ({worst[1]})")
+    # the test has teeth: the same statistics tell two different families' agents apart
+    shifted = (checks["agent0 cell"]["host"] + 1) % (w * h)
+    assert chi2_same(checks["agent0 cell"]["dev"], shifted, w * h) < 1e-6
+
+
+@pytest.mark.parametrize("family", ["redbluedoors", "blockedunlockpickup", "lockedhallway4"])
+def test_stepping_from_device_layouts(family):
+    """Header blocks written by the generator (front cells, door positions) are what the step kernel expects."""
+    from oracle.coracle import BatchOracle
+    from test_gpu_batch import compare, compare_state, rand_inputs
+    name, agents, kw = FAMILIES[family]
+    n = 3000
+    spec, gen, env, st = device_layouts(name, agents, dict(kw, max_steps=50), n, seed=3)
+    ora = BatchOracle(spec, n)
+    ora.load(np.arange(n), st["grid"], st["agents"], st["meta"])
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        actions, order = rand_inputs(rng, n, agents)
+        compare(env.step(actions, order), ora.step(actions, order), f"{family} step {t}")
+    compare_state(env, ora, family)
+    env.close()
+
+
+def test_generator_reports_rooms_that_are_too_full():
+    from multigrid_amd._lib import MgError
+    from multigrid_amd.batched import BatchedMultiGrid
+    spec, gen = envs.make_spec("MultiGrid-LockedHallway-2Rooms-v0", num_agents=12)
+    env = BatchedMultiGrid(spec, 8, device=0)
+    with pytest.raises(MgError, match="could not be completed"):
+        env.generate_layouts(gen, 64, seed=1)
+    env.close()
+
+
+def test_vector_env_on_device_layouts():
+    """One pool entry per environment, drawn on the device; episodes run and restart."""
+    import torch
+    from multigrid_amd.vector import MultiGridVectorEnv
+    n = 5000
+    venv = MultiGridVectorEnv("MultiGrid-BlockedUnlockPickup-v0", n, agents=2, num_layouts=n, seed=4,
+                              device_layouts=True, max_steps=20)
+    obs, _ = venv.reset()
+    assert obs["image"].shape == (n, 2, 7, 7, 3)
+    g = torch.Generator(device=obs["image"].device).manual_seed(0)
+    finished = 0
+    for t in range(45):
+        a = torch.randint(0, 7, (n, 2), generator=g, device=obs["image"].device, dtype=torch.uint8)
+        obs, rew, term, trunc, info = venv.step(a)
+        if "_final_info" in info:
+            finished += int(info["_final_info"].sum())
+            assert int(info["episode_length"].max()) <= 20
+    assert finished >= 2 * n
+    assert int(venv.stats()[0]) == finished
+    venv.close()
