@@ -1206,7 +1206,10 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
 // at a time for the observation passes.
 
 template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH>
-__global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
+#ifndef MG_KERNEL_ATTR
+#define MG_KERNEL_ATTR
+#endif
+__global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParams p) {
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int IMG = 3 * V * V;  // bytes per agent image
     const int lane = threadIdx.x;
@@ -1243,11 +1246,24 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
     // contiguous block of the state array, so the loads need no per-lane address arithmetic
     // beyond lane * 16; environments restarted in this launch are patched in from the pool
     // afterwards (fixup), which is rare enough to stay a plain loop.
-    uint4 gb0, gb1, gb2, gb3, gb4, gb5, gb6, gb7;
+    uint4 gb0, gb1, gb2, gb3, gb4;
+#if MG_PREFETCH_REGS != 5
+    uint4 gb5, gb6, gb7;
+#endif
 #define MG_ISSUE1(c, r) if ((c) * 64 < n16_) r = src_[min((c) * 64 + lane, n16_ - 1)];
 #define MG_COMMIT1(c, r) \
     if ((c) * 64 < n16_ && (c) * 64 + lane < n16_) dg_[(c) * 64 + lane + udiv((c) * 64 + lane, p.magic_per)] = r;
+// 16-byte registers per lane for the grid prefetch (1 KiB of a sub-tile's grids each; what exceeds them is
+// loaded when the sub-tile starts).  Five cover the sub-tiles of every registered configuration up to 16 x 16
+// cells x 8 agents and keep the kernel 19 registers smaller than eight do.
+#ifndef MG_PREFETCH_REGS
+#define MG_PREFETCH_REGS 5
+#endif
+#if MG_PREFETCH_REGS == 5
+#define MG_EACH(OP) OP(0, gb0) OP(1, gb1) OP(2, gb2) OP(3, gb3) OP(4, gb4)
+#else
 #define MG_EACH(OP) OP(0, gb0) OP(1, gb1) OP(2, gb2) OP(3, gb3) OP(4, gb4) OP(5, gb5) OP(6, gb6) OP(7, gb7)
+#endif
     auto issue = [&](int s0_) {
         const int n16_ = min(NE, net - s0_) * per;
         const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0 + s0_) * p.GS);
@@ -1258,10 +1274,10 @@ __global__ __launch_bounds__(64) void mg_tile_kernel(const KParams p) {
         const int n16_ = ns_ * per;
         uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
         MG_EACH(MG_COMMIT1)
-        if (n16_ > 512) {  // grids beyond 8 KiB per sub-tile
+        if (n16_ > 64 * MG_PREFETCH_REGS) {  // grids beyond what the prefetch registers hold
             const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0 + s0_) * p.GS);
 #pragma unroll 1
-            for (int i = 512 + lane; i < n16_; i += 64) dg_[i + udiv(i, p.magic_per)] = src_[i];
+            for (int i = 64 * MG_PREFETCH_REGS + lane; i < n16_; i += 64) dg_[i + udiv(i, p.magic_per)] = src_[i];
         }
         if (MODE != MODE_OBS && __ballot(lane < ns_ && lsrc[s0_ + lane] >= 0)) {
             // environments restarted in this launch: their grid comes from the layout pool
@@ -2049,8 +2065,10 @@ void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
 template <int MODE>
 int launch_tile(MgEnv *h, const KParams &kp, hipStream_t s) {
     switch (h->cfg.view_size) {
+#ifndef MG_ONLY_VIEW7  // tuning builds compile the 7 x 7 kernels alone
         case 3: launch_vm<3, MODE>(h, kp, s); break;
         case 5: launch_vm<5, MODE>(h, kp, s); break;
+#endif
         case 7: launch_vm<7, MODE>(h, kp, s); break;
         default: return fail(h, MG_EINVAL, "view_size %d not supported", h->cfg.view_size);
     }
