@@ -19,6 +19,9 @@ FAMILIES = {
     "blockedunlockpickup": ("MultiGrid-BlockedUnlockPickup-v0", 2, {}),
     "lockedhallway4": ("MultiGrid-LockedHallway-4Rooms-v0", 4, {}),
     "lockedhallway6": ("MultiGrid-LockedHallway-6Rooms-v0", 3, dict(max_hallway_keys=2)),
+    "lockedhallway2_room7": ("MultiGrid-LockedHallway-2Rooms-v0", 3, dict(room_size=7, max_keys_per_room=1)),
+    "blockedunlockpickup_room8": ("MultiGrid-BlockedUnlockPickup-v0", 5, dict(room_size=8)),
+    "redbluedoors6": ("MultiGrid-RedBlueDoors-6x6-v0", 4, {}),
 }
 
 
@@ -121,7 +124,7 @@ def test_structure_and_determinism(family):
         e.close()
 
 
-@pytest.mark.parametrize("family", ["empty_random", "redbluedoors", "blockedunlockpickup", "lockedhallway4", "lockedhallway6"])
+@pytest.mark.parametrize("family", [f for f in FAMILIES if f != "empty_fixed"])
 def test_distribution_matches_host_generators(family):
     import os
     name, agents, kw = FAMILIES[family]
