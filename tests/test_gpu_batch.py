@@ -30,6 +30,10 @@ CASES = {
     "crowd8_bup": ("MultiGrid-BlockedUnlockPickup-v0", 8, dict(max_steps=60, joint_reward=True)),
     "crowd6_lh": ("MultiGrid-LockedHallway-2Rooms-v0", 6, dict(max_steps=40)),
     "crowd16_lh": ("MultiGrid-LockedHallway-4Rooms-v0", 16, dict(max_steps=40, allow_agent_overlap=False)),
+    # hook-free environments finished inside the lane-per-agent pass: joint rewards, per-agent and joint termination
+    "joint8_empty": ("MultiGrid-Empty-5x5-v0", 8, dict(max_steps=30, joint_reward=True, success_termination_mode="all")),
+    "joint7_empty_any": ("MultiGrid-Empty-Random-5x5-v0", 7, dict(max_steps=25, joint_reward=True)),
+    "solo6_empty": ("MultiGrid-Empty-Random-6x6-v0", 6, dict(max_steps=25, success_termination_mode="all", failure_termination_mode="any")),
 }
 
 
@@ -117,7 +121,7 @@ def expected_layout(env_ids, episode, n_layouts, offset=0):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "odd3", "big10"])
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "odd3", "big10", "joint8_empty", "solo6_empty"])
 def test_autoreset_modes(case, mode):
     e, offset = 2500, 1000
     spec, pool, env, ora = make(case, e, autoreset=mode, env_id_offset=offset)
