@@ -132,6 +132,28 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     return out
 
 
+def memory_rates(dev):
+    """What this GPU's memory system gives plain streaming kernels: a device-to-device copy (bytes read +
+    bytes written per second) and a fill (bytes written per second), 1 GiB each, far beyond the caches."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * n), ("fill", lambda: a.fill_(1), n)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = moved * 10 / (e0.elapsed_time(e1) / 1e3) / 1e9
+    return out
+
+
 def cpu_leg(cfg_id, seconds=12.0):
     """The reference-style Python step loop (oracle/pyref.py, one env, one core) and the C port."""
     import numpy as np
@@ -237,6 +259,10 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_extra:
+        rates = memory_rates(torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))))
+        line["roofline"]["measured_copy_GBs"] = rates["copy"]
+        line["roofline"]["measured_fill_GBs"] = rates["fill"]
+        line["roofline"]["frac_of_measured_copy"] = achieved / rates["copy"]
         extra = []
         for cid in (2, 3, 4, 5):
             if cid == args.config:
