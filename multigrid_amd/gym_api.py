@@ -32,6 +32,42 @@ class Mission(str):
         return str(self)
 
 
+class BoxSpec:
+    """Stand-in for ``gymnasium.spaces.Box`` where gymnasium is not installed: ``low / high / shape / dtype``."""
+
+    def __init__(self, low, high, shape, dtype):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), np.dtype(dtype)
+
+    def contains(self, x) -> bool:
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(((x >= self.low) & (x <= self.high)).all())
+
+    def __repr__(self):
+        return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+
+class DiscreteSpec:
+    """Stand-in for ``gymnasium.spaces.Discrete``."""
+
+    def __init__(self, n: int):
+        self.n, self.shape, self.dtype = int(n), (), np.dtype(np.int64)
+
+    def contains(self, x) -> bool:
+        return 0 <= int(x) < self.n
+
+    def __repr__(self):
+        return f"Discrete({self.n})"
+
+
+def _spaces():
+    """gymnasium's own space classes when gymnasium can be imported, the stand-ins above otherwise."""
+    try:
+        from gymnasium import spaces  # noqa: PLC0415
+        return spaces.Box, spaces.Discrete, spaces.Dict
+    except Exception:  # gymnasium absent (or a name-only stand-in without these classes)
+        return BoxSpec, DiscreteSpec, dict
+
+
 class MultiGridEnv:
     metadata = {"render_modes": [], "render_fps": 20}
 
@@ -56,6 +92,28 @@ class MultiGridEnv:
         self.agent_names = []
         for team, n in self.teams.items():
             self.agent_names += [f"{team}_{i}" for i in range(n)]
+
+    # -- spaces -------------------------------------------------------------------------------------
+    def agent_observation_space(self, i: int = 0):
+        """One agent's observation space (multigrid/core/agent.py:116-128): image Box(0, 255, (V, V, 3), int),
+        direction Discrete(4); the mission space is left out (text, host side only)."""
+        box, discrete, dct = _spaces()
+        v = self.spec["view_size"]
+        return dct({"image": box(0, 255, (v, v, 3), np.int64), "direction": discrete(4)})
+
+    def agent_action_space(self, i: int = 0):
+        """multigrid/core/agent.py:144: Discrete(len(Action))."""
+        return _spaces()[1](7)
+
+    @property
+    def observation_space(self):
+        """Joint space keyed ``"{color}_{team_index}"`` (multigrid/base.py:262-265)."""
+        return _spaces()[2]({n: self.agent_observation_space(i) for i, n in enumerate(self.agent_names)})
+
+    @property
+    def action_space(self):
+        """multigrid/base.py:285."""
+        return _spaces()[2]({n: self.agent_action_space(i) for i, n in enumerate(self.agent_names)})
 
     # -- gym.Env ------------------------------------------------------------------------------------
     @property
@@ -169,6 +227,22 @@ class PettingZooWrapper:
     @property
     def possible_agents(self):
         return list(range(self.env.num_agents))
+
+    # The reference indexes its name-keyed joint spaces with the integer agent ids it uses everywhere else
+    # (multigrid/pettingzoo/__init__.py:66-70), which raises KeyError there; here an id selects that agent's space.
+    @property
+    def observation_spaces(self):
+        return {i: self.env.agent_observation_space(i) for i in range(self.env.num_agents)}
+
+    @property
+    def action_spaces(self):
+        return {i: self.env.agent_action_space(i) for i in range(self.env.num_agents)}
+
+    def observation_space(self, agent_id):
+        return self.env.agent_observation_space(int(agent_id))
+
+    def action_space(self, agent_id):
+        return self.env.agent_action_space(int(agent_id))
 
 
 def make(name: str, **kwargs) -> MultiGridEnv:

@@ -42,6 +42,12 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw)
             if "BlockedUnlockPickup" not in name:  # there the reference hands agents a random mission (parity unpinned)
                 assert str(o[0]["mission"]) == spec["mission"] and o[0]["mission"].string == spec["mission"]
         pz = PettingZooWrapper(env)
+        # spaces: names "{color}_{team_index}" (base.py:262-265), image Box(0, 255, (V, V, 3)), 7 actions
+        assert list(env.observation_space.keys()) == list(env.action_space.keys()) == env.agent_names
+        assert env.agent_names[0] == "red_0" and len(env.agent_names) == agents
+        sp = pz.observation_space(0)
+        assert sp["image"].shape == (7, 7, 3) and sp["image"].contains(o[0]["image"]) and sp["direction"].n == 4
+        assert pz.action_space(agents - 1).n == 7 and set(pz.action_spaces) == set(range(agents))
         assert pz.possible_agents == list(range(agents))
         assert pz.agents == ([] if env.is_done() else [i for i in range(agents) if not d["post_agents"][n, t, i, 3]])
         env.close()
