@@ -195,12 +195,42 @@ def cpu_leg(cfg_id, seconds=12.0):
             bo.load(ids, grid[None], ags[None], meta[None])
         m += 1
     c_rate = m * e * agents / (time.perf_counter() - t0)
+
+    # the same C port on every host core this process may use: one batch of environments per thread (the
+    # library call releases the interpreter lock), all threads stepping for the same 4 seconds
+    import threading
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    counts = [0] * cores
+    stop_at = time.perf_counter() + 4.0
+
+    def worker(k):
+        b = BatchOracle(spec, e)
+        b.load(np.arange(e), grid[None], ags[None], meta[None])
+        n_ = 0
+        while time.perf_counter() < stop_at:
+            b.step(acts[n_ % 8], order[n_ % 8])
+            n_ += 1
+        counts[k] = n_
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    c_all_rate = sum(counts) * e * agents / (time.perf_counter() - t0)
     return dict(
         value=py_rate, unit="agent-steps/s", cores=1, kind="port",
         sample=f"{n} steps of one {name} env ({agents} agents, uniform-random actions) through the Python "
                f"restatement of the reference step loop (oracle/pyref.py, vectorised gen_obs), {seconds:.0f} s",
         c_port_value=c_rate, c_port_cores=1,
-        c_port_sample=f"{m} batched steps of {e} envs through oracle/mg_oracle.c (gcc -O2, one thread)")
+        c_port_sample=f"{m} batched steps of {e} envs through oracle/mg_oracle.c (gcc -O2, one thread)",
+        c_port_all_cores_value=c_all_rate, c_port_all_cores=cores,
+        c_port_all_cores_sample=f"{sum(counts)} batched steps of {e} envs over {cores} threads, 4 s")
 
 
 def main():
