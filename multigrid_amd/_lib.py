@@ -51,7 +51,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
                                               os.path.getmtime(os.path.join(INCLUDE_DIR, "mgrid.h"))):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    # -Os, measured: the step kernel is 7 % faster than at -O3 (smaller code, and 126 instead of 129 vector
+    # registers, which lets a fourth wavefront onto every SIMD)
+    cmd = [hipcc, "-Os", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
