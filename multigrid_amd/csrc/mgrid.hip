@@ -57,7 +57,7 @@ constexpr uint32_t LAYOUT_STRIDE = 7919;  // layout of episode k of env g: (g + 
 constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 
 #ifndef MG_STAGE_LANES
-#define MG_STAGE_LANES 16
+#define MG_STAGE_LANES 32
 #endif
 // With few agents per environment the in-order replay (one lane per environment) is cheaper than the
 // lane-per-agent pass plus its bookkeeping; measured crossover on MI355X.
@@ -79,7 +79,9 @@ struct LdsMap {
     int R;      // [ET]      f64 _reward() of this step
     int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
     int grid;   // [NE][GS]      grids of the sub-tile being observed
-    int img;    // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order
+    int img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
+    int stage;  // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order: starts where `grid` starts
+                // (the grids are dead once a sub-tile has been observed) and runs on into `img`
     int oh;     // [192] uint4   one-hot pieces changing lanes (present only in launches that write one-hot images)
 };
 
@@ -1567,8 +1569,8 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                         __builtin_amdgcn_update_dpp(0, static_cast<int>(px_first), 0xF9, 0xF, 0xF, false));  // quad_perm [1,2,3,3]
                     px[M] = __builtin_amdgcn_alignbyte(next0 >> 8, (px[M] & 0xFFFFFFu) | (next0 << 24), j);
                 }
-                uint32_t *wdst = reinterpret_cast<uint32_t *>(lds + p.o.img) + ((lane & (STAGE_LANES - 1)) >> 2) * IMG + (M + 1) * j;
-                const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.img);
+                uint32_t *wdst = reinterpret_cast<uint32_t *>(lds + p.o.stage) + ((lane & (STAGE_LANES - 1)) >> 2) * IMG + (M + 1) * j;
+                const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.stage);
                 uint4 *dst16 = reinterpret_cast<uint4 *>(p.image + tile_base) + lane;
 #pragma unroll
                 for (int r = 0; r < 64 / STAGE_LANES; ++r) {
@@ -1588,7 +1590,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                                 if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it];
                         }
                         if (OH && p.onehot)
-                            emit_one_hot<V>(p, lds, lds + p.o.img, STAGE_LANES * V * V,
+                            emit_one_hot<V>(p, lds, lds + p.o.stage, STAGE_LANES * V * V,
                                             p.onehot + (tile_agent0 + r * STAGE_LANES) * (OH_DIM * V * V), lane, true, ~0ull,
                                             r * STAGE_LANES);
                         wave_sync();
@@ -1601,7 +1603,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                     const size_t out_base = tile_base + static_cast<size_t>(l0) * IMG;  // byte offset of the block
                     const int shift = p.image ? static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15) : 0;
                     if (mine && lane >= l0 && lane < l0 + nl) {
-                        uint8_t *dst = lds + p.o.img + shift + (lane - l0) * IMG;
+                        uint8_t *dst = lds + p.o.stage + shift + (lane - l0) * IMG;
 #pragma unroll
                         for (int k = 0; k + 4 <= NPX; k += 4) __builtin_memcpy(dst + 4 * k, &px[k], 16);
 #pragma unroll
@@ -1612,18 +1614,18 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                     const int total = shift + nl * IMG;
                     const int nchunk = p.image ? (total + 15) / 16 : 0;
                     if (OH && p.onehot)
-                        emit_one_hot<V>(p, lds, lds + p.o.img + shift, nl * V * V,
+                        emit_one_hot<V>(p, lds, lds + p.o.stage + shift, nl * V * V,
                                         p.onehot + (tile_agent0 + l0) * (OH_DIM * V * V), lane, false, sub_mask, l0);
 #pragma unroll 1
                     for (int c = lane; c < nchunk; c += 64) {
                         const int b0 = 16 * c;
                         if (all_active && b0 >= shift && b0 + 16 <= total) {
-                            *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o.img + b0);
+                            *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(lds + p.o.stage + b0);
                         } else {
                             for (int bb = b0; bb < b0 + 16; ++bb) {
                                 if (bb < shift || bb >= total) continue;
                                 const int slot = (l0 + (bb - shift) / IMG) / A;
-                                if ((sub_mask >> slot) & 1) gdst[bb] = lds[p.o.img + bb];
+                                if ((sub_mask >> slot) & 1) gdst[bb] = lds[p.o.stage + bb];
                             }
                         }
                     }
@@ -2154,18 +2156,21 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         kp.o.R = take(8 * et);
         kp.o.src = take(4 * et);
         kp.o.grid = take(ne * (kp.GS + 16));  // 16 bytes between grids spread them over the LDS banks
-        kp.o.img = take(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np));  // doubles as act_lanes() scratch
+        const int grids = round_up(ne * (kp.GS + 16), 16);
+        kp.o.stage = kp.o.grid;  // images are staged over the grids of the sub-tile they were made from
+        kp.o.img = take(std::max(std::min(np, STAGE_LANES) * img + 32 - grids, 8 * np));  // act_lanes() scratch + overflow
         return o;
     };
     // Measured on MI355X: with the in-order act phase (one lane per environment) about 32 environments
     // per wavefront balance lane use against LDS-limited occupancy; with the lane-per-agent act phase
-    // 16 are enough and leave room for more wavefronts per CU.
+    // 16 are enough and leave room for more wavefronts per CU, and one full sub-tile of 8 agents x 8
+    // environments is (slightly) better still.
     int ne = 64 / c.num_agents;
     const int want_waves = 2048;
     while (ne > 1 && (c.num_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
     while (ne > 1 && lds_for(ne, 1) > 40 * 1024) --ne;
     int g = 1;
-    const int et_target = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? 16 : 32;
+    const int et_target = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? (c.num_agents <= 8 ? 8 : 16) : 32;
     while ((g + 1) * ne <= et_target && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
