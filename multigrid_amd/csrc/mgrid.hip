@@ -2,16 +2,20 @@
 //
 // Execution model
 // ---------------
-// One 64-lane wavefront (= one workgroup) owns a TILE of NE consecutive environments with
-// NE * A <= 64, and runs four phases on it, all through LDS:
-//   stage    the tile's header block and grid block are copied HBM -> LDS with 16-byte loads;
-//   act      one lane per ENVIRONMENT replays the agents' actions in the given order
-//            (the reference's sequential handle_actions loop), then the environment hook;
+// One 64-lane wavefront (= one workgroup) owns G sub-tiles of NE consecutive environments each, with
+// NE * A <= 64 agent lanes per sub-tile, and runs four phases on them, all through LDS:
+//   stage    the header blocks and the first sub-tile's grids are copied HBM -> LDS with 16-byte loads;
+//   act      with six or more agents per environment, one lane per AGENT works out its action against
+//            the state at the start of the step; only the agents whose actions could interact are left
+//            for one lane per ENVIRONMENT to replay in the given order (the reference's sequential
+//            handle_actions loop), which also runs the environment hook; with fewer agents the
+//            in-order form does everything;
 //   observe  one lane per AGENT walks its V x V view over the LDS grid, runs the visibility
-//            scan on 7-bit row masks in registers and writes the image bytes into an LDS
-//            stream that mirrors the output tensor;
-//   write    the image stream leaves as aligned 16-byte stores, the per-agent scalars as one
-//            coalesced element per lane, and the header block as 16-byte stores.
+//            scan on 7-bit row masks in registers and keeps the image in registers;
+//   write    the images pass through an LDS buffer that mirrors the output tensor and leave as aligned
+//            16-byte stores (optionally also one-hot encoded), the per-agent scalars as one coalesced
+//            element per lane, and the header blocks as 16-byte stores.
+// A further kernel draws start states on the device (one thread per layout).
 //
 // Device state (per handle)
 // -------------------------
