@@ -69,6 +69,9 @@ constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 #define MG_PARALLEL_ACT_MIN_AGENTS 6
 #endif
 constexpr int PARALLEL_ACT_MIN_AGENTS = MG_PARALLEL_ACT_MIN_AGENTS;
+#ifndef MG_COPY_BATCH
+#define MG_COPY_BATCH 5
+#endif
 constexpr int STAGE_LANES = MG_STAGE_LANES;  // agents whose images share the LDS staging buffer; a multiple of 16
 
 struct LdsMap {
@@ -1586,12 +1589,16 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                         }
                         wave_sync();
                         if (p.image) {
-                            uint4 ob[MAXIT];  // all LDS reads first, then all stores
+                            constexpr int BATCH = MG_COPY_BATCH;  // LDS reads of a batch first, then its stores
 #pragma unroll
-                            for (int it = 0; it < MAXIT; ++it) ob[it] = src16[min(it * 64 + lane, CH - 1)];
+                            for (int b0 = 0; b0 < MAXIT; b0 += BATCH) {
+                                uint4 ob[BATCH];
 #pragma unroll
-                            for (int it = 0; it < MAXIT; ++it)
-                                if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it];
+                                for (int it = b0; it < min(b0 + BATCH, MAXIT); ++it) ob[it - b0] = src16[min(it * 64 + lane, CH - 1)];
+#pragma unroll
+                                for (int it = b0; it < min(b0 + BATCH, MAXIT); ++it)
+                                    if (it * 64 + 64 <= CH || lane < CH - it * 64) dst16[r * CH + it * 64] = ob[it - b0];
+                            }
                         }
                         if (OH && p.onehot)
                             emit_one_hot<V>(p, lds, lds + p.o.stage, STAGE_LANES * V * V,
