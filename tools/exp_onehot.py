@@ -26,3 +26,6 @@ if __name__ == "__main__":
     run("MultiGrid-Empty-16x16-v0", 8, 131072, False)
     run("MultiGrid-Empty-16x16-v0", 8, 131072, True)
     run("MultiGrid-LockedHallway-4Rooms-v0", 4, 65536, False)
+    run("MultiGrid-BlockedUnlockPickup-v0", 2, 65536, False)
+    run("MultiGrid-Empty-8x8-v0", 4, 65536, False)
+    run("MultiGrid-RedBlueDoors-8x8-v0", 8, 65536, False)
