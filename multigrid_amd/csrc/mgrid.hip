@@ -2036,6 +2036,7 @@ struct MgEnv {
     int num_layouts = 0;
     bool reset_done = false;
     bool pool_walled = false;
+    int force_stream = -1;  // tuning / test override of the streaming-store choice: 0 never, 1 always
     uint32_t step_serial = 0;
     uint32_t reset_serial = 0;
     int64_t launches = 0;
@@ -2111,7 +2112,7 @@ bool out_ok(const MgOut *out) {  // the one-hot image is written in 8-byte piece
     return !out || (reinterpret_cast<uintptr_t>(out->onehot_dev) & 7) == 0;
 }
 
-void set_out(KParams &kp, const MgOut *out, int view) {
+void set_out(KParams &kp, const MgOut *out, int view, int force_stream) {
     kp.image = out ? out->image_dev : nullptr;
     kp.onehot = out ? out->onehot_dev : nullptr;
     kp.direction = out ? out->direction_dev : nullptr;
@@ -2121,8 +2122,8 @@ void set_out(KParams &kp, const MgOut *out, int view) {
     // outputs large enough to be streamed past the caches (thresholds measured on MI355X)
     const size_t cells = static_cast<size_t>(kp.E) * kp.A() * view * view;
     kp.bits &= ~(3u << 21);
-    if (3 * cells > (4u << 20)) kp.bits |= 1u << 21;
-    if (OH_DIM * cells > (512u << 20)) kp.bits |= 1u << 22;
+    if (force_stream < 0 ? 3 * cells > (4u << 20) : force_stream != 0) kp.bits |= 1u << 21;
+    if (force_stream < 0 ? OH_DIM * cells > (512u << 20) : force_stream != 0) kp.bits |= 1u << 22;
 }
 
 }  // namespace
@@ -2208,6 +2209,7 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     while ((g + 1) * ne <= et_target && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
+    if (const char *ev = getenv("MGRID_STREAM")) h->force_stream = atoi(ev) != 0;  // tuning override: "0" / "1"
     if (const char *ev = getenv("MGRID_TILE")) {  // tuning override: "NE,G"
         int a = 0, b = 0;
         if (sscanf(ev, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && a * c.num_agents <= 64 && a * b <= 64) {
@@ -2393,7 +2395,7 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
     kp.layout_idx = layout_idx_dev;
     kp.mask = mask_dev;
     kp.serial = h->reset_serial;  // 0: first reset, episode counters start at 0
-    set_out(kp, out, h->cfg.view_size);
+    set_out(kp, out, h->cfg.view_size, h->force_stream);
     const int rc = launch_tile<MODE_RESET>(h, kp, static_cast<hipStream_t>(stream));
     if (rc != MG_OK) return rc;
     h->reset_serial++;
@@ -2415,7 +2417,7 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
     kp.actions = actions_dev;
     kp.order = order_dev;
     kp.serial = h->step_serial;
-    set_out(kp, out, h->cfg.view_size);
+    set_out(kp, out, h->cfg.view_size, h->force_stream);
     const int rc = launch_tile<MODE_STEP>(h, kp, static_cast<hipStream_t>(stream));
     if (rc != MG_OK) return rc;
     h->step_serial++;
@@ -2454,7 +2456,7 @@ int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
     if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_gen_obs: onehot_dev must be 8-byte aligned");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
-    set_out(kp, out, h->cfg.view_size);
+    set_out(kp, out, h->cfg.view_size, h->force_stream);
     return launch_tile<MODE_OBS>(h, kp, static_cast<hipStream_t>(stream));
 }
 

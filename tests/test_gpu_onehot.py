@@ -148,3 +148,37 @@ def test_step_n_equals_steps(case, mode):
         np.testing.assert_array_equal(out.truncated[t].cpu().numpy(), trunc, err_msg=where)
     compare_state(env, ora, f"{case} after step_n")
     env.close()
+
+
+@pytest.mark.parametrize("stream", ["0", "1"])
+@pytest.mark.parametrize("case", ["cfg3", "cfg5", "odd5"])
+def test_streaming_stores_either_way(case, stream, monkeypatch):
+    """Image and one-hot stores take their non-temporal form above a size; both forms forced here."""
+    import torch
+    from multigrid_amd import envs, layouts
+    from multigrid_amd.batched import BatchedMultiGrid
+    from oracle.coracle import BatchOracle
+
+    monkeypatch.setenv("MGRID_STREAM", stream)
+    name, agents, extra = CASES[case]
+    spec, gen = envs.make_spec(name, num_agents=agents, **extra)
+    pool = layouts.make_pool(gen, 32, seed0=13)
+    e = 4096
+    env = BatchedMultiGrid(spec, e, device=0, one_hot=True, autoreset=2)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    ora = BatchOracle(spec, e)
+    rng = np.random.default_rng(14)
+    idx = rng.integers(0, len(pool[0]), size=e)
+    env.reset(layout_idx=idx)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    for t in range(12):
+        actions, order = rand_inputs(rng, e, agents)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        torch.cuda.synchronize()
+        compare(out, res, f"{case} stream={stream} step {t}")
+        np.testing.assert_array_equal(out.onehot.cpu().numpy(), oh(res[0]), err_msg=f"{case} stream={stream} step {t} one-hot")
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            break
+    env.close()
