@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
 """Throughput of the batched MultiGrid step on MI355X, next to a CPU port of the reference loop.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1..5] [--envs E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2..5] [--envs E] [--scaling weak|strong]
 
 One "step" = one ``mg_step`` launch over every environment of the rank (actions already in
 HBM, uniform random on {0..6}; agent order drawn on the device; episodes that end restart from
-a pool of 1024 host-generated layouts inside the same launch).  For N > 1 launch with
-``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``: every rank holds
-its own shard of environments (no data-path collective); the only collective is one RCCL
-all-reduce of the 64-byte episode-statistics vector after the timed region.
+a pool of 1024 host-generated layouts inside the same launch; the environments start at step
+counts scattered over [0, max_steps) so that episodes end at the steady-state rate from the
+first timed step on).
 
-Default workload: the per-GPU shard of BASELINE configs[4] - MultiGrid-Empty-16x16-v0,
-8 agents, 131072 environments per GPU (2^20 over 8 GPUs) - with weak scaling.  ``--config``
-selects the other BASELINE configurations at their stated sizes.
+``--gpus N`` with N > 1 starts N fresh processes, one per GPU, from a parent that never touches
+a GPU (or joins the ranks that ``python -m torch.distributed.run --nproc-per-node N`` already
+started): every rank holds its own shard of environments, there is no data-path collective, and
+the only exchange is one RCCL all-reduce of the 64-byte episode-statistics vector (plus a
+three-word check vector) after the timed region.  ``--scaling weak`` (default) keeps the per-GPU
+batch fixed (config 5: 131072 environments per GPU, 2^20 on 8 GPUs = BASELINE configs[4]);
+``--scaling strong`` splits the BASELINE total over the N GPUs.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,51 +33,54 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
-# BASELINE.json configs: name, agents, environments per GPU, extra kwargs
+# BASELINE.json configs: name, agents, environments per GPU (weak scaling), BASELINE total, extra kwargs
 CONFIGS = {
-    1: ("MultiGrid-Empty-8x8-v0", 2, 1, {}),
-    2: ("MultiGrid-RedBlueDoors-8x8-v0", 2, 4096, {}),
-    3: ("MultiGrid-BlockedUnlockPickup-v0", 2, 65536, {}),
-    4: ("MultiGrid-LockedHallway-4Rooms-v0", 4, 65536, {}),   # 262144 over 4 GPUs
-    5: ("MultiGrid-Empty-16x16-v0", 8, 131072, {}),           # 2^20 over 8 GPUs
+    1: ("MultiGrid-Empty-8x8-v0", 2, 1, 1, {}),
+    2: ("MultiGrid-RedBlueDoors-8x8-v0", 2, 4096, 4096, {}),
+    3: ("MultiGrid-BlockedUnlockPickup-v0", 2, 65536, 65536, {}),
+    4: ("MultiGrid-LockedHallway-4Rooms-v0", 4, 65536, 262144, {}),   # 262144 over 4 GPUs
+    5: ("MultiGrid-Empty-16x16-v0", 8, 131072, 1 << 20, {}),          # 2^20 over 8 GPUs
 }
 
 
-def algorithmic_bytes_per_env_step(spec, one_hot=False) -> int:
-    """Bytes one environment step has to move with uint8 fields, one step per launch:
-    actions + order in, image + direction + reward + terminated + truncated out (156 per agent),
-    agent rows and environment scalars in and out, the whole grid in, changed cells out.
-    With one-hot observations the 3-byte cells of the image leave as 24 bytes each."""
+def algorithmic_bytes_per_env_step(spec, one_hot=False, steps_per_launch=1) -> float:
+    """Bytes one environment step has to move with uint8 fields: actions + order in, image + direction +
+    reward + terminated + truncated out (156 per agent), and - once per launch - agent rows and environment
+    scalars in and out, the whole grid in, changed cells out.  With one-hot observations the 3-byte cells of
+    the image leave as 24 bytes each."""
     a, w, h, v = spec["num_agents"], spec["width"], spec["height"], spec["view_size"]
     img = v * v * (24 if one_hot else 3)
-    return (9 + img) * a + 2 * (8 * a + 8) + 3 * w * h + 3 * a
+    return (9 + img) * a + (2 * (8 * a + 8) + 3 * w * h + 3 * a) / steps_per_launch
 
 
-def measured_traffic(cfg_id, num_envs):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), when one
+def measured_traffic(name, num_envs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic*.json), when one
     matches this workload; the counters cannot be read from inside this process."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json"))):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        name = CONFIGS[cfg_id][0]
-        if name in d.get("workload", "") and f"{num_envs} envs" in d.get("workload", ""):
-            best = d.get("hbm_bytes_per_launch")
+        for rec in (d if isinstance(d, list) else [d]):
+            w = rec.get("workload", "")
+            if name in w and f"{num_envs} envs" in w and "overlap" not in w and "one-hot" not in w:
+                best = rec.get("hbm_bytes_per_launch")
     return best
 
 
-def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one_hot=False, **override):
-    import numpy as np
+def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one_hot=False, repeats=1,
+            steps_per_launch=1, **override):
+    """Times `repeats` runs of `steps` step launches each (every run bracketed by a barrier and a device
+    synchronisation on both sides, maximum over ranks) and returns the median run."""
     import torch
 
     from multigrid_amd import _lib, envs, layouts
     from multigrid_amd.batched import BatchedMultiGrid
 
-    name, agents, _, kw = CONFIGS[cfg_id]
-    spec, gen = envs.make_spec(name, num_agents=agents, **dict(kw, **override))
+    name, agents, _, _, kw = CONFIGS[cfg_id]
+    spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **dict(kw, **override))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
     env = BatchedMultiGrid(spec, num_envs, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
@@ -81,14 +90,31 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     env.reset()
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    ring = 16
+    # episodes in every phase of their life: ends (and restarts from the pool) arrive at the steady-state rate
+    env.set_state(steps=torch.randint(0, spec["max_steps"], (num_envs,), generator=g, device=dev, dtype=torch.int32))
+    T = steps_per_launch
+    ring = 16 if T == 1 else 2 * T
     actions = torch.randint(0, 7, (ring, num_envs, agents), generator=g, device=dev, dtype=torch.uint8)
+    outn = None
+    if T > 1:
+        from multigrid_amd.batched import StepOutput
+        e, a, v = num_envs, agents, spec["view_size"]
+        outn = StepOutput(image=torch.empty((T, e, a, v, v, 3), dtype=torch.uint8, device=dev),
+                          direction=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
+                          reward=torch.empty((T, e, a), dtype=torch.float32, device=dev),
+                          terminated=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
+                          truncated=torch.empty((T, e, a), dtype=torch.uint8, device=dev))
 
     def run(n, t0=0):
-        for t in range(n):
-            env.step(actions[(t0 + t) % ring])
+        if T == 1:
+            for t in range(n):
+                env.step(actions[(t0 + t) % ring])
+        else:
+            assert n % T == 0
+            for t in range(n // T):
+                env.step_n(actions[(t % 2) * T:(t % 2 + 1) * T], out=outn, fused=True)
 
-    run(warmup)
+    run(warmup if T == 1 else max(T, warmup // T * T))
     graphed = None
     if graph:
         # replay `ring` launches per graph launch; the step kernel keeps no host-side state
@@ -100,36 +126,78 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
             with torch.cuda.graph(graphed, stream=s):
                 run(ring)
         torch.cuda.current_stream(dev).wait_stream(s)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    wall0 = time.perf_counter()
-    ev0.record()
-    if graphed is not None:
-        assert steps % ring == 0
-        for _ in range(steps // ring):
-            graphed.replay()
-    else:
-        run(steps, warmup)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - wall0
-    gpu_s = ev0.elapsed_time(ev1) / 1e3
-    if world > 1:
-        torch.distributed.barrier()
-        t = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        wall, gpu_s = float(t[0]), float(t[1])
+    walls, gpus = [], []
+    for rep in range(repeats):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        wall0 = time.perf_counter()
+        ev0.record()
+        if graphed is not None:
+            assert steps % ring == 0
+            for _ in range(steps // ring):
+                graphed.replay()
+        else:
+            run(steps, warmup + rep * steps)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - wall0
+        gpu_s = ev0.elapsed_time(ev1) / 1e3
+        if world > 1:
+            torch.distributed.barrier()
+            t = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            wall, gpu_s = float(t[0]), float(t[1])
+        walls.append(wall)
+        gpus.append(gpu_s)
+    mid = sorted(range(repeats), key=lambda i: walls[i])[repeats // 2]
     stats = env.stats()
-    if world > 1:  # the path's only collective: 64 bytes over RCCL, off the step path
-        torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
-    stats = stats.cpu().numpy()
-    out = dict(spec=spec, name=name, agents=agents, num_envs=num_envs, wall=wall, gpu_s=gpu_s,
-               stats=stats, lds=None)
+    check = torch.tensor([1, steps, int(stats[5])], dtype=torch.int64, device=dev)
+    if world > 1:  # the path's only collective: 64 + 24 bytes over RCCL, off the step path
+        from multigrid_amd import distributed
+        distributed.allreduce_stats(stats)
+        torch.distributed.all_reduce(check, op=torch.distributed.ReduceOp.SUM)
+    out = dict(spec=spec, name=name, agents=agents, num_envs=num_envs, wall=walls[mid], gpu_s=gpus[mid],
+               walls=walls, stats=stats.cpu().numpy(), check=check.cpu().tolist(), max_steps=spec["max_steps"])
     env.close()
     return out
+
+
+def latency_one_env(args):
+    """BASELINE configs[0]: one MultiGrid-Empty-8x8 environment, 2 agents - the cost of a single step launch
+    (enqueue to completion, one synchronising step at a time) and the back-to-back launch interval."""
+    import torch
+
+    from multigrid_amd import _lib, envs, layouts
+    from multigrid_amd.batched import BatchedMultiGrid
+
+    name, agents, _, _, kw = CONFIGS[1]
+    spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    env = BatchedMultiGrid(spec, 1, device=dev, autoreset=_lib.AUTORESET_SAME_STEP, seed=1)
+    grids, ags, metas, _ = layouts.make_pool(gen, 4, seed0=0)
+    env.upload_layouts(grids, ags, metas)
+    env.reset()
+    acts = torch.randint(0, 7, (64, 1, agents), device=dev, dtype=torch.uint8)
+    for t in range(50):
+        env.step(acts[t % 64])
+    torch.cuda.synchronize(dev)
+    lat = []
+    for t in range(200):
+        t0 = time.perf_counter()
+        env.step(acts[t % 64])
+        torch.cuda.synchronize(dev)
+        lat.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for t in range(2000):
+        env.step(acts[t % 64])
+    torch.cuda.synchronize(dev)
+    interval = (time.perf_counter() - t0) / 2000
+    env.close()
+    return dict(workload=f"{name}, {agents} agents, 1 env", sync_step_latency_us=statistics.median(lat) * 1e6,
+                back_to_back_launch_us=interval * 1e6, agent_steps_per_s=agents / interval)
 
 
 def memory_rates(dev):
@@ -154,16 +222,15 @@ def memory_rates(dev):
     return out
 
 
-def cpu_leg(cfg_id, seconds=12.0):
-    """The reference-style Python step loop (oracle/pyref.py, one env, one core) and the C port."""
+def pyref_rate(cfg_id, seconds):
+    """The reference-style Python step loop (oracle/pyref.py, one environment, one core)."""
     import numpy as np
 
     from multigrid_amd import envs
     from oracle import pyref
-    from oracle.coracle import BatchOracle
 
-    name, agents, _, kw = CONFIGS[cfg_id]
-    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+    name, agents, _, _, kw = CONFIGS[cfg_id]
+    spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
     rng = np.random.default_rng(0)
     grid, ags, meta, _ = gen(mixin_rng=np.random.default_rng(0), env_rng=np.random.default_rng(100))
     env = pyref.Env(pyref.EnvSpec(**spec), fast_obs=True)
@@ -178,7 +245,22 @@ def cpu_leg(cfg_id, seconds=12.0):
             if env.is_done():
                 env.load_layout(grid, ags, meta)
             n += 1
-    py_rate = n * agents / (time.perf_counter() - t0)
+    return n * agents / (time.perf_counter() - t0), n, name, agents
+
+
+def cpu_leg(cfg_id, seconds=10.0):
+    """The reference-style Python step loop (oracle/pyref.py, one env, one core) and the C port."""
+    import numpy as np
+
+    from multigrid_amd import envs
+    from oracle.coracle import BatchOracle
+
+    py_rate, n, name, agents = pyref_rate(cfg_id, seconds)
+    py1_rate, n1, name1, agents1 = pyref_rate(1, 4.0)
+    _, _, _, _, kw = CONFIGS[cfg_id]
+    spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
+    rng = np.random.default_rng(0)
+    grid, ags, meta, _ = gen(mixin_rng=np.random.default_rng(0), env_rng=np.random.default_rng(100))
 
     e = 4096
     bo = BatchOracle(spec, e)
@@ -227,62 +309,161 @@ def cpu_leg(cfg_id, seconds=12.0):
         value=py_rate, unit="agent-steps/s", cores=1, kind="port",
         sample=f"{n} steps of one {name} env ({agents} agents, uniform-random actions) through the Python "
                f"restatement of the reference step loop (oracle/pyref.py, vectorised gen_obs), {seconds:.0f} s",
+        config1_plumbing_value=py1_rate, config1_plumbing_cores=1,
+        config1_plumbing_sample=f"{n1} steps of one {name1} env ({agents1} agents), same loop, 4 s (BASELINE configs[0])",
         c_port_value=c_rate, c_port_cores=1,
         c_port_sample=f"{m} batched steps of {e} envs through oracle/mg_oracle.c (gcc -O2, one thread)",
         c_port_all_cores_value=c_all_rate, c_port_all_cores=cores,
         c_port_all_cores_sample=f"{sum(counts)} batched steps of {e} envs over {cores} threads, 4 s")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", type=int, default=5, choices=[2, 3, 4, 5])
     ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the BASELINE size)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the per-GPU batch stays fixed; strong: the BASELINE total is split over the GPUs")
     ap.add_argument("--layouts", type=int, default=1024)
     ap.add_argument("--graph", action="store_true", help="replay the launches from a HIP graph")
+    ap.add_argument("--fused", type=int, default=1, metavar="T",
+                    help="T > 1: one fused launch per T steps (mg_step_n) instead of one launch per step")
+    ap.add_argument("--repeats", type=int, default=0, help="timed runs of --steps launches; the median is reported "
+                    "(default: 5 when --steps < 200, else 1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs")
-    args = ap.parse_args()
+    ap.add_argument("--selftest-gloo", action="store_true",
+                    help="exercise the multi-process launcher and the collectives on the CPU (gloo); no GPU, no kernel")
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args, argv) -> int:
+    """Parent of a multi-GPU run: starts one fresh process per rank and relays rank 0's line.  It makes no GPU
+    call itself (it does not even import torch), and no process is replaced by another."""
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        rc = 0
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                if p.poll() is not None:
+                    alive.remove(p)
+                    if p.returncode != 0:
+                        rc = rc or p.returncode
+            if rc and alive:  # a rank died: the others would wait for it forever
+                for p in alive:
+                    p.kill()
+                for p in alive:
+                    p.wait()
+                alive = []
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    return rc
+
+
+def selftest_gloo(args, rank, world):
+    """The launcher path, the process group and both collectives on the CPU: every rank reports `steps`
+    pretend launches; the printed line has the same keys as a real one."""
     import torch
+    import torch.distributed as dist
 
+    from multigrid_amd import distributed
+    if os.environ.get("MGRID_SELFTEST_FAIL_RANK") == str(rank):  # a rank that dies before the first collective
+        sys.exit(7)
+    stats = torch.tensor([0, 0, 0, 0, 0, args.steps + args.warmup, 0, 0], dtype=torch.int64)
+    check = torch.tensor([1, args.steps, args.steps + args.warmup], dtype=torch.int64)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+        distributed.allreduce_stats(stats)
+        dist.all_reduce(check, op=dist.ReduceOp.SUM)
+    wall = max(time.perf_counter() - t0, 1e-9)
+    ok = check.tolist()[:2] == [world, world * args.steps]
+    if rank == 0:
+        print(json.dumps({"metric": "agent_steps_per_sec", "value": 0.0, "unit": "agent-steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / max(1, args.steps) * 1e3,
+                          "higher_is_better": True, "scaling": args.scaling, "selftest": True, "backend": "gloo",
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                          "collective_check": {"ranks_seen": check[0].item(), "steps_sum": check[1].item(),
+                                               "launches_sum": check[2].item(), "ok": ok},
+                          "stats_launches": int(stats[5])}))
+    return 0 if ok else 3
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if args.gpus > 1:
-        if world != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
-                             f"(WORLD_SIZE={world})")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args, argv)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    name, agents, base_envs, _ = CONFIGS[args.config]
-    num_envs = args.envs or base_envs
-    r = gpu_leg(args, args.config, num_envs, rank, world, args.steps, args.warmup, graph=args.graph)
+    import torch
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.selftest_gloo:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    if args.selftest_gloo:
+        rc = selftest_gloo(args, rank, world)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return rc
+
+    name, agents, per_gpu, total, _ = CONFIGS[args.config]
+    num_envs = args.envs or (per_gpu if args.scaling == "weak" else max(1, total // world))
+    repeats = args.repeats or (5 if args.steps < 200 else 1)
+    T = max(1, args.fused)
+    r = gpu_leg(args, args.config, num_envs, rank, world, args.steps, args.warmup, graph=args.graph, repeats=repeats,
+                steps_per_launch=T)
     spec = r["spec"]
     total_agent_steps = world * num_envs * agents * args.steps
     value = total_agent_steps / r["wall"]
-    launch_s = r["gpu_s"] / args.steps
-    bytes_step = algorithmic_bytes_per_env_step(spec)
-    achieved = num_envs * bytes_step / launch_s / 1e9
+    launch_s = r["gpu_s"] / (args.steps / T)
+    bytes_step = algorithmic_bytes_per_env_step(spec, steps_per_launch=T)
+    achieved = num_envs * bytes_step * T / launch_s / 1e9
+    traffic = measured_traffic(name, num_envs) if T == 1 else None
+    ranks_seen, steps_sum, launches_sum = r["check"]
 
     line = {
         "metric": "agent_steps_per_sec", "value": value, "unit": "agent-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": r["wall"] / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "repeats": repeats, "ms_per_step_all_repeats": [w / args.steps * 1e3 for w in r["walls"]],
         "config": {"workload": f"{name}, {agents} agents, 7x7 view, {num_envs} envs per GPU "
                                f"({world * num_envs} total), uniform-random actions, on-device agent order, "
-                               f"same-step auto-reset from {args.layouts} layouts",
+                               f"same-step auto-reset from {args.layouts} layouts, start step counts scattered "
+                               f"over [0, {r['max_steps']})",
                    "baseline_config": args.config, "envs_per_gpu": num_envs, "agents": agents,
-                   "grid": [spec["width"], spec["height"]], "steps_per_launch": 1,
+                   "grid": [spec["width"], spec["height"]], "steps_per_launch": T,
                    "launch": "hip_graph" if args.graph else "eager", "parallelism": f"env-shard x{world}"},
+        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+        "collective_check": {"ranks_seen": ranks_seen, "steps_sum": steps_sum, "launches_sum": launches_sum,
+                             "ok": ranks_seen == world and steps_sum == world * args.steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, num_envs),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from profiles/",
-                     "kernel": "mg_tile_kernel", "algorithmic_bytes_per_env_step": bytes_step,
-                     "launch_us": launch_s * 1e6},
+                     "frac_counter_bytes": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "kernel": "mg_tile_kernel" if T == 1 else "mg_rollout_kernel",
+                     "algorithmic_bytes_per_env_step": bytes_step, "launch_us": launch_s * 1e6},
         "episode_stats": {"episodes": int(r["stats"][0]), "mean_length": float(r["stats"][1]) / max(1, int(r["stats"][0])),
                           "terminated": int(r["stats"][2]), "truncated": int(r["stats"][3]),
                           "reward_sum": float(r["stats"][4]) / 2 ** 24},
@@ -294,29 +475,41 @@ def main():
         line["roofline"]["measured_fill_GBs"] = rates["fill"]
         line["roofline"]["frac_of_measured_copy"] = achieved / rates["copy"]
         extra = []
+
+        def add(cid, e2, label="", n_steps=400, n_warm=50, one_hot=False, **kw):
+            n2, a2 = CONFIGS[cid][0], CONFIGS[cid][1]
+            Tx = kw.get("steps_per_launch", 1)
+            x = gpu_leg(args, cid, e2, 0, 1, n_steps, n_warm, one_hot=one_hot, **kw)
+            ls = x["gpu_s"] / (n_steps / Tx)
+            b2 = algorithmic_bytes_per_env_step(x["spec"], one_hot=one_hot, steps_per_launch=Tx)
+            tr = measured_traffic(n2, e2) if not label else None
+            extra.append({"baseline_config": cid, "workload": f"{n2}, {a2} agents, {e2} envs" + (", " + label if label else ""),
+                          "value": e2 * a2 * n_steps / x["wall"], "launch_us": ls * 1e6, "steps_per_launch": Tx,
+                          "algorithmic_bytes_per_env_step": b2,
+                          "roofline_frac": e2 * b2 * Tx / ls / 1e9 / HBM_PEAK_GBS,
+                          "roofline_frac_counter_bytes": (tr / ls / 1e9 / HBM_PEAK_GBS) if tr else None,
+                          "episodes": int(x["stats"][0])})
+
         for cid in (2, 3, 4, 5):
-            if cid == args.config:
-                continue
-            n2, a2, e2, _ = CONFIGS[cid]
-            x = gpu_leg(args, cid, e2, 0, 1, 400, 50)
-            ls = x["gpu_s"] / 400
-            b2 = algorithmic_bytes_per_env_step(x["spec"])
-            extra.append({"baseline_config": cid, "workload": f"{n2}, {a2} agents, {e2} envs",
-                          "value": e2 * a2 * 400 / x["wall"], "launch_us": ls * 1e6,
-                          "roofline_frac": e2 * b2 / ls / 1e9 / HBM_PEAK_GBS})
+            if cid != args.config:
+                add(cid, CONFIGS[cid][2])
+        # the literal BASELINE batches of configs[3] and configs[4] on ONE GPU: working sets far beyond the
+        # 256 MiB Infinity Cache
+        add(4, CONFIGS[4][3], n_steps=200, n_warm=20)
+        add(5, CONFIGS[5][3], n_steps=200, n_warm=20)
         # configs[4] again with agents blocking each other, and with one-hot observations
         # (OneHotObsWrapper, multigrid/wrappers.py:60-146) written by the step launch instead of the compact image
-        n5, a5, e5, _ = CONFIGS[5]
-        for label, kw5, oh in (("allow_agent_overlap=False", dict(allow_agent_overlap=False), False),
-                               ("one-hot observations (V,V,24)", {}, True)):
-            x = gpu_leg(args, 5, e5, 0, 1, 200, 30, one_hot=oh, **kw5)
-            ls = x["gpu_s"] / 200
-            b5 = algorithmic_bytes_per_env_step(x["spec"], one_hot=oh)
-            extra.append({"baseline_config": 5, "workload": f"{n5}, {a5} agents, {e5} envs, {label}",
-                          "value": e5 * a5 * 200 / x["wall"], "launch_us": ls * 1e6,
-                          "algorithmic_bytes_per_env_step": b5,
-                          "roofline_frac": e5 * b5 / ls / 1e9 / HBM_PEAK_GBS})
+        add(5, CONFIGS[5][2], "allow_agent_overlap=False", 200, 30, allow_agent_overlap=False)
+        add(5, CONFIGS[5][2], "one-hot observations (V,V,24)", 200, 30, one_hot=True)
+        # launch-bound batches: the same steps replayed from a HIP graph, and fused into one launch per T steps
+        for cid in (2, 3, 4):
+            add(cid, CONFIGS[cid][2], "HIP graph of 16 launches", 400, 48, graph=True)
+        if hasattr(__import__("multigrid_amd._lib", fromlist=["x"]), "HAVE_FUSED_STEP_N"):
+            for cid in (2, 3, 4):
+                for Tx in (8, 64):
+                    add(cid, CONFIGS[cid][2], f"fused launch of {Tx} steps", 384, 64, steps_per_launch=Tx)
         line["other_configs"] = extra
+        line["config1_one_env"] = latency_one_env(args)
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_leg(args.config)
         line["cpu_baseline"]["host_cpus"] = os.cpu_count()
@@ -324,7 +517,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0 if line["collective_check"]["ok"] else 3
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -21,7 +21,8 @@
  *                                redbluedoors.py:161-168); zeros for the other kinds
  *   image    uint8 [E][A][V][V][3]  obs["image"] of multigrid/base.py:430-436 (int64 there)
  *   onehot   uint8 [E][A][V][V][24] the same image one-hot encoded, multigrid/wrappers.py:114-146
- * Cell fields are limited to type < 16, state < 16, color < 128 (the reference uses 11 / 7 / 6).
+ * Cell fields (and the carried object and colour of an agent row) are limited to type < 16, state < 16,
+ * color < 16 (the reference uses 11 / 7 / 6); mg_upload_layouts and mg_set_state refuse anything larger.
  */
 #ifndef MGRID_H
 #define MGRID_H
@@ -58,14 +59,17 @@ typedef struct MgConfig {
     int32_t kind;                /* MG_KIND_* */
     int32_t width, height;       /* grid size W, H                      base.py:162-165 */
     int32_t num_agents;          /* A                                    base.py:172-178 */
-    int32_t view_size;           /* V: 3, 5 or 7                         base.py:96 */
+    int32_t view_size;           /* V: 3, 5 or 7 only (the reference takes any odd size; its default is 5,
+                                    its registry entries never set it); MG_EINVAL otherwise   base.py:96 */
     int32_t max_steps;           /*                                      base.py:94 */
     int32_t see_through_walls;   /*                                      base.py:95 */
     int32_t allow_agent_overlap; /*                                      base.py:97 */
     int32_t joint_reward;        /*                                      base.py:98 */
     int32_t success_any;         /* success_termination_mode == "any"    base.py:99 */
     int32_t failure_any;         /* failure_termination_mode == "any"    base.py:100 */
-    int32_t num_rooms;           /* LockedHallway only                   locked_hallway.py:129 */
+    int32_t num_rooms;           /* LockedHallway only, 1..6: rewarded doors are tracked by door colour and
+                                    the reference has six colours (it cycles them beyond six rooms,
+                                    which is not supported: MG_EINVAL)    locked_hallway.py:129,160-166 */
     int32_t num_envs;            /* E: environments held by this handle */
     int32_t device;              /* HIP device ordinal */
     int32_t autoreset;           /* MG_AUTORESET_* */
@@ -99,7 +103,9 @@ const char *mg_last_error(MgHandle h);
 
 /* Uploads N start states produced on the host by the `_gen_grid` layout generators
  * (multigrid/envs/empty.py:152, redbluedoors.py:141, blockedunlockpickup.py:136,
- * locked_hallway.py:146).  HOST pointers; copied, synchronous. */
+ * locked_hallway.py:146).  HOST pointers; copied, synchronous.  `meta` may be NULL except for
+ * MG_KIND_REDBLUEDOORS, whose hook needs the door positions: there it must name a red door and a blue door
+ * of the layout's grid (MG_EINVAL otherwise). */
 int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, const uint8_t *meta,
                       int32_t n);
 
@@ -156,7 +162,9 @@ int mg_gen_obs(MgHandle h, const MgOut *out, void *stream);
  * steps int32[E] = step_count (base.py:350,395); flags uint8[E]: bits 0-5 LockedHallway doors
  * already rewarded, by door colour (locked_hallway.py:204-205); bit 7: RedBlueDoors blue door
  * object re-closed after a failure while its grid cell still reads open (redbluedoors.py:185).
- * Any pointer may be NULL. */
+ * Any pointer may be NULL.  mg_set_state first checks `grid_dev` and `agents_dev` against the field limits
+ * at the top of this file (waiting for the stream) and returns MG_EINVAL, leaving the state untouched, when a
+ * value does not fit. */
 int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *meta_dev,
                  int32_t *steps_dev, uint8_t *flags_dev, void *stream);
 int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,

@@ -106,6 +106,8 @@ class BatchedMultiGrid:
         n = grids.shape[0]
         if grids.shape != (n, self.W, self.H, 3) or agents.shape != (n, self.A, 8):
             raise ValueError(f"bad layout shapes {grids.shape} {agents.shape}")
+        if meta is None and int(self.spec["kind"]) == _lib.KIND_REDBLUEDOORS:
+            raise ValueError("RedBlueDoors layouts need `meta`: the red and blue door positions the hook looks at")
         meta = np.zeros((n, 4), np.uint8) if meta is None else np.ascontiguousarray(meta, np.uint8)
         check(_lib.lib().mg_upload_layouts(self._h, grids.ctypes.data, agents.ctypes.data,
                                            meta.ctypes.data, n), self._h)

@@ -116,7 +116,6 @@ struct KParams {
     uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
     uint32_t env_offset;
     uint64_t seed;
-    double reward_slope;  // 0.9 / max_steps
     uint32_t serial;  // reset launches so far (0: the first reset starts the episode counters)
     // state
     uint8_t *hdr;
@@ -234,6 +233,19 @@ __device__ __forceinline__ uint32_t order_key(const KParams &p, int env, uint32_
 __device__ __forceinline__ uint32_t order_field(uint32_t key, int f, uint32_t &word) {
     if ((f & 1) == 0) word = fmix32(key + static_cast<uint32_t>((f >> 1) + 1) * 0x9E3779B9u);
     return (word >> (16 * (f & 1))) & 0xFFFF;
+}
+
+// _reward(), multigrid/base.py:655-659, in the reference's own order of operations (the quotient first), so
+// that the double is the one Python computes
+__device__ __forceinline__ double step_reward(const KParams &p, int step) {
+    return 1.0 - 0.9 * (static_cast<double>(step) / static_cast<double>(p.max_steps));
+}
+
+// rewards[k] after `m` additions of R to 0 (multigrid/envs/locked_hallway.py:207-211 repeats `+=`)
+__device__ __forceinline__ double reward_times(double R, int m) {
+    double v = 0.0;
+    for (int j = 0; j < m; ++j) v += R;
+    return v;
 }
 
 // ---- act: one lane per environment -------------------------------------------------------------
@@ -426,8 +438,7 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     const uint32_t was_over = ev.flags & FLAG_OVER;
     const uint32_t blue_xy = h0.w >> 16;
     const bool rbd = p.kind() == MG_KIND_REDBLUEDOORS;
-    reinterpret_cast<double *>(lds + p.o.R)[slot] =
-        1.0 - static_cast<double>(step) * p.reward_slope;  // 1 - 0.9 * (step_count / max_steps), base.py:655-659
+    reinterpret_cast<double *>(lds + p.o.R)[slot] = step_reward(p, step);
 
     // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
     const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
@@ -673,7 +684,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     const uint32_t was_over = flags & FLAG_OVER;
     const uint32_t red_xy = h0.w & 0xFFFF, blue_xy = h0.w >> 16;
     const bool rbd = p.kind() == MG_KIND_REDBLUEDOORS;
-    const double R = 1.0 - static_cast<double>(step) * p.reward_slope;  // 1 - 0.9 * (step_count / max_steps), base.py:655-659
+    const double R = step_reward(p, step);
     reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
 
     // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
@@ -964,7 +975,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                 reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
                     static_cast<uint16_t>(ev.nv);
             if (my_agent == 0) {
-                const double R = 1.0 - static_cast<double>(step) * p.reward_slope;  // base.py:655-659
+                const double R = step_reward(p, step);
                 const uint32_t flags = h0.z & 0xFF;
                 *reinterpret_cast<int *>(h + H_STEP) = step;
                 h[H_FLAGS] = static_cast<uint8_t>(flags | (over ? FLAG_OVER : 0u));
@@ -1687,7 +1698,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
         if (p.direction) p.direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
         if (MODE == MODE_STEP) {
             if (p.reward)
-                p.reward[o] = static_cast<float>(lds[p.o.rewm + s] * reinterpret_cast<const double *>(lds + p.o.R)[slot]);
+                p.reward[o] = static_cast<float>(reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]));
             if (p.terminated) p.terminated[o] = lds[p.o.tout + s];
             if (p.truncated) p.truncated[o] = lds[p.o.flag + 4 * slot];
         }
@@ -1751,6 +1762,22 @@ __global__ void mg_set_state_kernel(KParams p, const uint8_t *grid, const uint8_
                 for (int k = 0; k < p.A() * 8; ++k) h[H_ROWS + k] = agents[e * p.A() * 8 + k];
         }
     }
+}
+
+// Fields the packed formats cannot hold (type, colour, state above 15; a heading above 3): counted, so
+// that mg_set_state can refuse the state instead of truncating it.
+__global__ void mg_validate_state_kernel(KParams p, const uint8_t *grid, const uint8_t *agents, int *bad) {
+    const size_t cells = static_cast<size_t>(p.E) * p.W() * p.H(), rows = static_cast<size_t>(p.E) * p.A();
+    int n = 0;
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < cells;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        if (grid) n += (grid[3 * i] > 15) | (grid[3 * i + 1] > 15) | (grid[3 * i + 2] > 15);
+        if (agents && i < rows) {
+            const uint8_t *r = agents + 8 * i;
+            n += (r[R_DIR] > 3) | (r[R_CT] > 15) | (r[R_CC] > 15) | (r[R_CS] > 15) | (r[R_COLOR] > 15);
+        }
+    }
+    if (n) atomicAdd(bad, n);
 }
 
 // Recompute the front cells kept in the header blocks from the grid (after mg_set_state).
@@ -2134,10 +2161,13 @@ int mg_abi_version(void) { return MG_ABI_VERSION; }
 
 const char *mg_last_error(MgHandle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int mg_create(const MgConfig *cfg, MgHandle *out) {
-    if (!cfg || !out) return fail(nullptr, MG_EINVAL, "mg_create: null argument");
-    *out = nullptr;
-    const MgConfig &c = *cfg;
+}  // extern "C"
+
+namespace {
+
+// Everything mg_create derives from the configuration without touching a device: validation, packed
+// kernel parameters, tile shape, LDS map.  Errors go to the creation-error text.
+int configure(MgEnv *h, const MgConfig &c) {
     if (c.kind < 0 || c.kind > MG_KIND_LOCKEDHALLWAY) return fail(nullptr, MG_EINVAL, "unknown kind %d", c.kind);
     if (c.width < 3 || c.height < 3 || c.width > 255 || c.height > 255 || c.width * c.height > 4096)
         return fail(nullptr, MG_EINVAL, "grid %dx%d not supported (3..255 per side, at most 4096 cells)", c.width,
@@ -2153,8 +2183,6 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     if (c.kind == MG_KIND_LOCKEDHALLWAY && (c.num_rooms < 1 || c.num_rooms > 6))
         return fail(nullptr, MG_EINVAL, "LockedHallway needs 1..6 rooms (one door colour each), got %d", c.num_rooms);
 
-    MgEnv *h = new (std::nothrow) MgEnv();
-    if (!h) return fail(nullptr, MG_EINVAL, "out of host memory");
     h->cfg = c;
     KParams &kp = h->kp;
     kp.geo = static_cast<uint32_t>(c.width) | (static_cast<uint32_t>(c.height) << 8) |
@@ -2169,7 +2197,6 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
     kp.GS = round_up(2 * c.width * c.height, 16);
     kp.env_offset = static_cast<uint32_t>(c.env_id_offset);
     kp.seed = c.seed;
-    kp.reward_slope = 0.9 / static_cast<double>(c.max_steps);
 
     // Tile shape.  NE environments per observation pass give at most 64 agent lanes; one wavefront
     // owns G such sub-tiles so that its act phase (one lane per environment) fills up to 64 lanes.
@@ -2225,25 +2252,41 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         if (kp.dbg & 32) h->lds_bytes = static_cast<size_t>(kp.o.grid);  // act phase alone
     }
 #endif
-    if (h->lds_bytes + OH_XCHG_BYTES > 64 * 1024) {
-        const size_t need = h->lds_bytes;
-        delete h;
-        return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", need);
-    }
+    if (h->lds_bytes + OH_XCHG_BYTES > 64 * 1024)
+        return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", h->lds_bytes);
     kp.geo |= static_cast<uint32_t>(ne) << 24;
     kp.bits |= static_cast<uint32_t>(g) << 12;
     kp.magic_a = c.num_agents == 1 ? 0u : 0xFFFFFFFFu / c.num_agents + 1u;
     kp.magic_nc = 0xFFFFFFFFu / (c.num_agents + 2) + 1u;
     kp.magic_per = kp.GS == 16 ? 0u : 0xFFFFFFFFu / (kp.GS / 16) + 1u;
     h->num_tiles = (c.num_envs + ne * g - 1) / (ne * g);
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_create(const MgConfig *cfg, MgHandle *out) {
+    if (!cfg || !out) return fail(nullptr, MG_EINVAL, "mg_create: null argument");
+    *out = nullptr;
+    MgEnv *h = new (std::nothrow) MgEnv();
+    if (!h) return fail(nullptr, MG_EINVAL, "out of host memory");
+    const int rc = configure(h, *cfg);
+    if (rc != MG_OK) {
+        delete h;
+        return rc;
+    }
+    const MgConfig &c = h->cfg;
+    KParams &kp = h->kp;
 
     hipError_t e = hipSetDevice(c.device);
     if (e == hipSuccess) e = hipMalloc(&h->hdr, static_cast<size_t>(c.num_envs) * kp.HS);
     if (e == hipSuccess) e = hipMalloc(&h->grid, static_cast<size_t>(c.num_envs) * kp.GS);
-    if (e == hipSuccess) e = hipMalloc(&h->stats, 64 * MG_NUM_STATS * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&h->stats, (64 * MG_NUM_STATS + 1) * sizeof(int64_t));  // + mg_set_state's counter
     if (e == hipSuccess) e = hipMemset(h->hdr, 0, static_cast<size_t>(c.num_envs) * kp.HS);
     if (e == hipSuccess) e = hipMemset(h->grid, 0, static_cast<size_t>(c.num_envs) * kp.GS);
-    if (e == hipSuccess) e = hipMemset(h->stats, 0, 64 * MG_NUM_STATS * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMemset(h->stats, 0, (64 * MG_NUM_STATS + 1) * sizeof(int64_t));
     if (e != hipSuccess) {
         fail(nullptr, MG_EHIP, "mg_create: %s", hipGetErrorString(e));
         mg_destroy(h);
@@ -2269,6 +2312,8 @@ int mg_destroy(MgHandle h) {
 int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, const uint8_t *meta, int32_t n) {
     if (!h) return MG_EINVAL;
     if (!grids || !agents || n < 1) return fail(h, MG_EINVAL, "mg_upload_layouts: null pointer or n < 1");
+    if (h->kp.kind() == MG_KIND_REDBLUEDOORS && !meta)
+        return fail(h, MG_EINVAL, "mg_upload_layouts: RedBlueDoors layouts need `meta` (the red and blue door positions)");
     const KParams &kp = h->kp;
     const int cells = kp.W() * kp.H(), A = kp.A();
     std::vector<uint8_t> ph(static_cast<size_t>(n) * kp.HS, 0), pg(static_cast<size_t>(n) * kp.GS, 0);
@@ -2310,6 +2355,10 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
                 return fail(h, MG_EINVAL, "layout %d door position outside the grid", l);
             fc[A] = gd[m[0] * kp.H() + m[1]];
             fc[A + 1] = gd[m[2] * kp.H() + m[3]];
+            // Color.red = 0, Color.blue = 2 (multigrid/core/constants.py:50-59)
+            if ((fc[A] & 0x0F0F) != (T_DOOR | (0u << 8)) || (fc[A + 1] & 0x0F0F) != (T_DOOR | (2u << 8)))
+                return fail(h, MG_EINVAL, "layout %d: meta does not name a red door at (%d,%d) and a blue door at (%d,%d)", l,
+                            m[0], m[1], m[2], m[3]);
         }
     }
     MG_HIP(h, hipSetDevice(h->cfg.device));
@@ -2478,6 +2527,19 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
     MG_HIP(h, hipSetDevice(h->cfg.device));
     const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W() * h->kp.H();
     const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 65535));
+    if (grid_dev || agents_dev) {
+        // a state the packed formats cannot hold is refused as a whole (this waits for the stream)
+        int *bad_dev = reinterpret_cast<int *>(h->stats + 64 * MG_NUM_STATS), bad = 0;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        MG_HIP(h, hipMemsetAsync(bad_dev, 0, sizeof(int), st));
+        hipLaunchKernelGGL(mg_validate_state_kernel, dim3(blocks), dim3(256), 0, st, h->kp, grid_dev, agents_dev, bad_dev);
+        MG_HIP(h, hipGetLastError());
+        MG_HIP(h, hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        MG_HIP(h, hipStreamSynchronize(st));
+        if (bad)
+            return fail(h, MG_EINVAL, "mg_set_state: %d cells or agent rows exceed type<16, color<16, state<16, dir<4; "
+                        "nothing was changed", bad);
+    }
     hipLaunchKernelGGL(mg_set_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
                        grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);
     MG_HIP(h, hipGetLastError());

@@ -47,14 +47,14 @@ def agent_colors(teams: Dict[str, int]):
 
 
 def make_spec(name: str, num_agents: int | None = None, teams: Dict[str, int] | None = None,
-              agent_view_size: int = 7, **kwargs) -> Tuple[dict, Callable]:
+              agent_view_size: int = 5, **kwargs) -> Tuple[dict, Callable]:
     """Spec + layout generator for a registered configuration.
 
     ``kwargs`` are the reference's constructor arguments (``max_steps``, ``joint_reward``,
     ``allow_agent_overlap``, ``success_termination_mode``, ``failure_termination_mode``,
     ``see_through_walls`` and the per-family ``size`` / ``room_size`` / ``num_rooms`` ...).
-    Note that the reference's base default for ``agent_view_size`` is 5 (multigrid/base.py:96);
-    the benchmark configurations all pass 7.
+    ``agent_view_size`` defaults to 5 like the reference's base class (multigrid/base.py:96; no registry
+    entry overrides it); the benchmark configurations all pass 7.
     """
     family, reg = CONFIGURATIONS[name]
     kw = dict(reg, **kwargs)

@@ -72,7 +72,7 @@ class MultiGridEnv:
     metadata = {"render_modes": [], "render_fps": 20}
 
     def __init__(self, name: str, agents: Optional[int] = None, teams: Optional[Dict[str, int]] = None,
-                 agent_view_size: int = 7, device: int | str = 0, layout_rng: Optional[np.random.Generator] = None,
+                 agent_view_size: int = 5, device: int | str = 0, layout_rng: Optional[np.random.Generator] = None,
                  **kwargs):
         self.name = name
         self.spec, self._gen = envs.make_spec(name, num_agents=agents, teams=teams,
@@ -143,6 +143,16 @@ class MultiGridEnv:
         out = self._sim.step(acts, order)
         self.step_count += 1
         rew = out.reward[0].cpu().numpy().astype(np.float64)
+        # The device returns float32.  Every reward of a step is a whole number of _reward() values
+        # (multigrid/base.py:655-659; LockedHallway adds one per door, locked_hallway.py:207-211), so the
+        # reference's double is recomputed here from the step count and that number.
+        unit = 1 - 0.9 * (self.step_count / self.max_steps)
+        if unit != 0:
+            for i in np.nonzero(rew)[0]:
+                total = 0.0
+                for _ in range(int(round(rew[i] / unit))):
+                    total += unit
+                rew[i] = total
         term = out.terminated[0].cpu().numpy().astype(bool)
         trunc = out.truncated[0].cpu().numpy().astype(bool)
         st = self._sim.get_state()

@@ -71,7 +71,10 @@ class MultiGridVectorEnv:
     def reset(self, seed: Optional[int] = None, options=None):
         """Start every environment on a fresh episode.  ``seed`` selects the pool of start states (layout k of
         the pool is drawn with generator seed ``seed + k``); without it the pool of the last reset is kept."""
-        self._layouts(self._seed if seed is None else int(seed))
+        if seed is not None:
+            self._layouts(int(seed))
+        elif self._uploaded is None:
+            self._layouts(self._seed)
         out = self._sim.reset()
         self._ret.zero_()
         self._len.zero_()

@@ -5,6 +5,7 @@ Runs only in the build container (needs ``/root/reference``); the GPU box and
 the test-suite read the ``.npz`` files this script writes next to itself.
 
     python tests/golden/make_golden.py            # regenerate every group
+    python tests/golden/make_golden.py NAME ...   # only the named groups ("layouts" for layouts.npz)
 
 The reference needs numba / aenum / pygame / gymnasium / ray, none of which is
 installed here; ``refshim/`` supplies name-only stand-ins (see its README) so
@@ -183,8 +184,13 @@ def face_doors_with_keys(env, rng):
 
 # --- recording ---------------------------------------------------------------
 
+ONLY = set(sys.argv[1:])  # group names to (re)generate; empty = all
+
+
 def record_group(name, build_env, n_traj, t_max, seed0, edit=None, action_p=None,
                  extra_after_done=3, script=None):
+    if ONLY and name not in ONLY:
+        return
     rng = np.random.default_rng(seed0)
     trajs = []
     spec = None
@@ -313,6 +319,11 @@ def main():
     record_group("short_lockedhallway2", lambda: make_env(LockedHallwayEnv, 2, num_rooms=2, max_steps=30), 4, 36, 20,
                  action_p=BIASED)
 
+    # the registry entry constructed with the reference's own defaults (agent_view_size 5, base.py:96)
+    record_group("default_empty8",
+                 lambda: EmptyEnv(agents=2, teams=teams_for(2), policies_map={}, **cfg["MultiGrid-Empty-8x8-v0"][1]),
+                 3, 40, 21)
+
     # ---- harness-edited start states
     allk = ["goal", "lava", "floor", "wall", "key", "ball", "box", "door_open", "door_closed", "door_locked"]
 
@@ -400,7 +411,8 @@ def main():
                  12, 50, 45, edit=lh_edit, action_p=TOGGLY, script=lh_script)
     record_group("chaos_lockedhallway6", lambda: make_env(LockedHallwayEnv, 6, num_rooms=6, max_steps=100),
                  6, 60, 46, edit=lh_edit, action_p=TOGGLY, script=lh_script)
-    record_layouts()
+    if not ONLY or "layouts" in ONLY:
+        record_layouts()
 
 
 def _ck(entry, agents):

@@ -28,9 +28,9 @@ WORKER = textwrap.dedent("""
     rank, world = D.init("gloo")
     assert world == 2
     start, count = D.shard_range(1000, rank, world)
-    stats = torch.tensor([count, start, rank + 1, 0, 0, 0, 0, 7], dtype=torch.int64)
+    stats = torch.tensor([count, start, rank + 1, 0, 0, 40 + rank, 0, 7], dtype=torch.int64)
     D.allreduce_stats(stats)
-    assert stats.tolist() == [1000, 500, 3, 0, 0, 0, 0, 14], stats.tolist()
+    assert stats.tolist() == [1000, 500, 3, 0, 0, 41, 0, 14], stats.tolist()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     print("rank", rank, "ok")
@@ -53,3 +53,28 @@ def test_stats_allreduce_two_ranks_gloo(tmp_path):
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out
         assert "ok" in out
+
+
+def test_bench_launcher_two_ranks_gloo():
+    """`python bench.py --gpus 2` as the driver starts it: the parent spawns the ranks itself; here on the CPU
+    (gloo) with the kernels left out, so that the launcher, the process group and both collectives run."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "3",
+                        "--selftest-gloo"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 9
+    assert line["collective_check"] == {"ranks_seen": 2, "steps_sum": 18, "launches_sum": 24, "ok": True}
+    assert line["stats_launches"] == 12  # the maximum over ranks, not their sum
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies must not leave the others waiting in a collective: the parent ends them and fails."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "9", "--selftest-gloo"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
+                       env=dict(env, MGRID_SELFTEST_FAIL_RANK="1"))
+    assert p.returncode != 0 and "{" not in p.stdout

@@ -50,7 +50,7 @@ def make(case, num_envs, n_layouts=64, table=None, **kw):
     from oracle.coracle import BatchOracle
 
     name, agents, extra = (table or CASES)[case]
-    spec, gen = envs.make_spec(name, num_agents=agents, **extra)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))
     pool = layouts.make_pool(gen, n_layouts, seed0=7)
     env = BatchedMultiGrid(spec, num_envs, device=0, **kw)
     env.upload_layouts(pool[0], pool[1], pool[2])
@@ -268,6 +268,28 @@ def test_set_state_roundtrip_and_errors():
     bad[0, 0, 0, 0] = 99
     with pytest.raises(MgError):
         env.upload_layouts(bad, pool[1][:4], pool[2][:4])
+    # a state the packed cells cannot hold is refused as a whole, not truncated
+    bad_grid = pool[0][idx].copy()
+    bad_grid[3, 2, 2, 1] = 16
+    with pytest.raises(MgError, match="nothing was changed"):
+        env.set_state(grid=bad_grid)
+    bad_agents = st_agents = env.get_state()["agents"].cpu().numpy().copy()
+    bad_agents[7, 1, 5] = 200
+    with pytest.raises(MgError):
+        env.set_state(agents=bad_agents)
+    compare_state(env, ora, "after refused set_state")
+    env.close()
+
+
+def test_redbluedoors_layouts_need_door_positions():
+    from multigrid_amd._lib import MgError
+    spec, pool, env, ora = make("cfg2", 8)
+    with pytest.raises(ValueError):
+        env.upload_layouts(pool[0], pool[1])
+    meta = pool[2].copy()
+    meta[5] = 0  # the corner wall is neither door
+    with pytest.raises(MgError, match="red door"):
+        env.upload_layouts(pool[0], pool[1], meta)
     env.close()
 
 

@@ -63,9 +63,9 @@ def test_extreme_sizes(case, mode):
 def test_limits_are_reported():
     from multigrid_amd._lib import MgError
     from multigrid_amd.batched import BatchedMultiGrid
-    spec, _ = envs.make_spec("MultiGrid-Empty-8x8-v0", num_agents=2, size=70)  # 4900 cells
+    spec, _ = envs.make_spec("MultiGrid-Empty-8x8-v0", num_agents=2, size=70, agent_view_size=7)  # 4900 cells
     with pytest.raises(MgError, match="not supported"):
         BatchedMultiGrid(spec, 4, device=0)
-    spec, _ = envs.make_spec("MultiGrid-Empty-8x8-v0", num_agents=65)
+    spec, _ = envs.make_spec("MultiGrid-Empty-8x8-v0", num_agents=65, agent_view_size=7)
     with pytest.raises(MgError, match="num_agents"):
         BatchedMultiGrid(spec, 4, device=0)

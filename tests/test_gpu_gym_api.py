@@ -14,6 +14,8 @@ CASES = [
     ("cfg3_blockedunlockpickup", "MultiGrid-BlockedUnlockPickup-v0", 2, 13, {}),
     ("cfg4_lockedhallway4", "MultiGrid-LockedHallway-4Rooms-v0", 4, 15, {}),
     ("cfg5_empty16", "MultiGrid-Empty-16x16-v0", 8, 17, {}),
+    # constructed with the reference's own defaults: 5 x 5 views (multigrid/base.py:96)
+    ("default_empty8", "MultiGrid-Empty-8x8-v0", 2, 21, {"agent_view_size": None}),
 ]
 
 
@@ -22,6 +24,12 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw)
     from multigrid_amd.gym_api import MultiGridEnv, PettingZooWrapper, RLlibWrapper
 
     spec, d = load_group(group)
+    kw = dict(kw)
+    if kw.get("agent_view_size", 7) is None:
+        kw.pop("agent_view_size")  # the facade's default must be the reference's
+    else:
+        kw.setdefault("agent_view_size", 7)
+    view = spec["view_size"]
     for n in range(min(3, len(d["length"]))):
         env = MultiGridEnv(name, agents=agents, layout_rng=np.random.default_rng(seed0 * 1000 + n), **kw)
         obs, infos = env.reset(seed=seed0 * 7919 + n)
@@ -35,7 +43,7 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw)
             np.testing.assert_array_equal(np.stack([o[i]["image"] for i in range(agents)]), d["image"][n, t],
                                           err_msg=f"{group}[{n}] step {t}")
             assert [int(o[i]["direction"]) for i in range(agents)] == list(d["direction"][n, t])
-            np.testing.assert_allclose([r[i] for i in range(agents)], d["reward"][n, t], atol=1e-6, rtol=0)
+            assert [float(r[i]) for i in range(agents)] == list(d["reward"][n, t])  # the reference's doubles, bit for bit
             assert [bool(term[i]) for i in range(agents)] == list(d["terminated"][n, t])
             assert [trunc[i] for i in range(agents)] == list(d["truncated"][n, t])
             assert term["__all__"] == all(d["terminated"][n, t]) and trunc["__all__"] == all(d["truncated"][n, t])
@@ -46,7 +54,7 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw)
         assert list(env.observation_space.keys()) == list(env.action_space.keys()) == env.agent_names
         assert env.agent_names[0] == "red_0" and len(env.agent_names) == agents
         sp = pz.observation_space(0)
-        assert sp["image"].shape == (7, 7, 3) and sp["image"].contains(o[0]["image"]) and sp["direction"].n == 4
+        assert sp["image"].shape == (view, view, 3) == o[0]["image"].shape and sp["image"].contains(o[0]["image"]) and sp["direction"].n == 4
         assert pz.action_space(agents - 1).n == 7 and set(pz.action_spaces) == set(range(agents))
         assert pz.possible_agents == list(range(agents))
         assert pz.agents == ([] if env.is_done() else [i for i in range(agents) if not d["post_agents"][n, t, i, 3]])

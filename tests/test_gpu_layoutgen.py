@@ -27,7 +27,7 @@ FAMILIES = {
 
 def device_layouts(name, agents, kw, n, seed):
     from multigrid_amd.batched import BatchedMultiGrid
-    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **kw))
     env = BatchedMultiGrid(spec, n, device=0)
     env.generate_layouts(gen, n, seed=seed)
     env.reset(layout_idx=np.arange(n))
@@ -190,7 +190,7 @@ def test_stepping_from_device_layouts(family):
 def test_generator_reports_rooms_that_are_too_full():
     from multigrid_amd._lib import MgError
     from multigrid_amd.batched import BatchedMultiGrid
-    spec, gen = envs.make_spec("MultiGrid-LockedHallway-2Rooms-v0", num_agents=12)
+    spec, gen = envs.make_spec("MultiGrid-LockedHallway-2Rooms-v0", num_agents=12, agent_view_size=7)
     env = BatchedMultiGrid(spec, 8, device=0)
     with pytest.raises(MgError, match="could not be completed"):
         env.generate_layouts(gen, 64, seed=1)
@@ -203,7 +203,7 @@ def test_vector_env_on_device_layouts():
     from multigrid_amd.vector import MultiGridVectorEnv
     n = 5000
     venv = MultiGridVectorEnv("MultiGrid-BlockedUnlockPickup-v0", n, agents=2, num_layouts=n, seed=4,
-                              device_layouts=True, max_steps=20)
+                              device_layouts=True, max_steps=20, agent_view_size=7)
     obs, _ = venv.reset()
     assert obs["image"].shape == (n, 2, 7, 7, 3)
     g = torch.Generator(device=obs["image"].device).manual_seed(0)

@@ -57,7 +57,7 @@ def test_one_hot_large_batches(case, compact):
     import torch
 
     name, agents, extra = CASES[case]
-    spec, gen = envs.make_spec(name, num_agents=agents, **extra)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))
     pool = layouts.make_pool(gen, 32, seed0=11)
     e = 2222
     env = BatchedMultiGrid(spec, e, device=0, one_hot=True, compact_image=compact)
@@ -161,7 +161,7 @@ def test_streaming_stores_either_way(case, stream, monkeypatch):
 
     monkeypatch.setenv("MGRID_STREAM", stream)
     name, agents, extra = CASES[case]
-    spec, gen = envs.make_spec(name, num_agents=agents, **extra)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))
     pool = layouts.make_pool(gen, 32, seed0=13)
     e = 4096
     env = BatchedMultiGrid(spec, e, device=0, one_hot=True, autoreset=2)

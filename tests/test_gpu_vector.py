@@ -27,8 +27,8 @@ def test_vector_env_contract(name, agents, single, kw):
 
     n, n_layouts, seed = 700, 48, 21
     venv = MultiGridVectorEnv(name, n, agents=agents, device=0, num_layouts=n_layouts, seed=seed,
-                              single_agent=single, numpy=True, one_hot=True, **kw)
-    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+                              single_agent=single, numpy=True, one_hot=True, agent_view_size=7, **kw)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **kw))
     pool = layouts.make_pool(gen, n_layouts, seed0=seed)
     ora = BatchOracle(spec, n)
     ids_all = np.arange(n)

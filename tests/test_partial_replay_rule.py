@@ -79,7 +79,7 @@ def marked_agents(env, acts, overlap):
     ("MultiGrid-Empty-5x5-v0", 8, dict(max_steps=30, allow_agent_overlap=False, success_termination_mode="all"), 30),
 ])
 def test_unmarked_first_equals_sequential(name, agents, kw, seeds):
-    spec, gen = envs.make_spec(name, num_agents=agents, **kw)
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **kw))
     sp = pyref.EnvSpec(**spec)
     replayed = 0
     for seed in range(seeds):

@@ -7,7 +7,7 @@ from multigrid_amd.batched import BatchedMultiGrid
 
 for name, agents in (("MultiGrid-Empty-Random-6x6-v0", 3), ("MultiGrid-RedBlueDoors-8x8-v0", 2),
                      ("MultiGrid-BlockedUnlockPickup-v0", 2), ("MultiGrid-LockedHallway-4Rooms-v0", 4)):
-    spec, gen = envs.make_spec(name, num_agents=agents)
+    spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7)
     env = BatchedMultiGrid(spec, 64, device=0)
     env.generate_layouts(gen, 1024, seed=0)
     torch.cuda.synchronize()

@@ -6,7 +6,7 @@ from multigrid_amd import envs, layouts
 from multigrid_amd.batched import BatchedMultiGrid
 
 def run(cfg, agents, e, compact, steps=100):
-    spec, gen = envs.make_spec(cfg, num_agents=agents)
+    spec, gen = envs.make_spec(cfg, num_agents=agents, agent_view_size=7)
     env = BatchedMultiGrid(spec, e, device=0, autoreset=1, seed=1, one_hot=True, compact_image=compact)
     pool = layouts.make_pool(gen, 256)
     env.upload_layouts(*pool[:3]); env.reset()

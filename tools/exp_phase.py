@@ -6,7 +6,7 @@ from multigrid_amd import _lib, envs, layouts
 from multigrid_amd.batched import BatchedMultiGrid, StepOutput
 
 def run(cfg, agents, e, variant, steps=200):
-    spec, gen = envs.make_spec(cfg, num_agents=agents)
+    spec, gen = envs.make_spec(cfg, num_agents=agents, agent_view_size=7)
     env = BatchedMultiGrid(spec, e, device=0, autoreset=1, seed=1)
     pool = layouts.make_pool(gen, 256)
     env.upload_layouts(*pool[:3]); env.reset()

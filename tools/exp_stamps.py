@@ -10,7 +10,7 @@ NAMES = {1: "hdr->LDS", 2: "act", 3: "resets+scalars", 4: "pass0: grid->LDS", 5:
          7: "pass0: observe", 8: "pass0: copy-out", 9: "remaining passes", 10: "hdr->HBM"}
 
 def run(cfg, agents, e, **kw):
-    spec, gen = envs.make_spec(cfg, num_agents=agents, **kw)
+    spec, gen = envs.make_spec(cfg, num_agents=agents, agent_view_size=7, **kw)
     env = BatchedMultiGrid(spec, e, device=0, autoreset=1, seed=1)
     pool = layouts.make_pool(gen, 256)
     env.upload_layouts(*pool[:3]); env.reset()

@@ -19,7 +19,7 @@ def run(cid, tile, steps=300):
         os.environ["MGRID_TILE"] = tile
     else:
         os.environ.pop("MGRID_TILE", None)
-    spec, gen = envs.make_spec(cfg, num_agents=agents)
+    spec, gen = envs.make_spec(cfg, num_agents=agents, agent_view_size=7)
     env = BatchedMultiGrid(spec, e, device=0, autoreset=1, seed=1)
     pool = layouts.make_pool(gen, 256)
     env.upload_layouts(*pool[:3]); env.reset()
