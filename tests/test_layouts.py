@@ -36,11 +36,15 @@ def test_layout_generator_matches_reference(name):
     ("cfg5_empty16", "MultiGrid-Empty-16x16-v0", 8, {}),
     ("cfg5_empty16_nooverlap", "MultiGrid-Empty-16x16-v0", 8, {"allow_agent_overlap": False}),
     ("short_lockedhallway2", "MultiGrid-LockedHallway-2Rooms-v0", 2, {"max_steps": 30}),
+    ("default_empty8", "MultiGrid-Empty-8x8-v0", 2, {"agent_view_size": None}),  # the reference's own default view
 ])
 def test_registry_spec_matches_reference_env(group, name, agents, kw):
     """make_spec() derives the same geometry and flags the reference classes report about themselves."""
     from golden_util import load_group
     ref_spec, _ = load_group(group)
+    kw = dict(kw)
+    if kw.setdefault("agent_view_size", 7) is None:  # the recorded BASELINE groups pass 7 explicitly
+        kw.pop("agent_view_size")
     spec, _ = envs.make_spec(name, num_agents=agents, **kw)
     ref_spec.pop("mission")
     spec.pop("mission")
