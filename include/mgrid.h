@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 3
+#define MG_ABI_VERSION 4
 
 /* error codes */
 #define MG_OK 0
@@ -157,6 +157,22 @@ int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const u
 /* Replaces MultiGridEnv.gen_obs (multigrid/base.py:410-438): image and direction of the current
  * state of every environment. */
 int mg_gen_obs(MgHandle h, const MgOut *out, void *stream);
+
+/* mg_gen_obs for a state that the CALLER holds, in the reference's layouts (grid_dev uint8 [E][W][H][3],
+ * agents_dev uint8 [E][A][8], device pointers), instead of the state inside a handle; `cfg` gives num_envs,
+ * width, height, num_agents, view_size, see_through_walls and device (the other fields are ignored), `out`
+ * takes image / direction / onehot as in mg_gen_obs.
+ * This entry point has no counterpart in the reference.  It exists for callers that cannot allocate device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It needs no
+ * handle and calls no hipMalloc / hipFree: the packed copy of the state that the observation kernel reads
+ * lives in a fixed 8 MiB buffer inside the library (one per GPU, held until the process ends).  A call
+ * whose environments do not fit (num_envs * (header + grid bytes), e.g. 13442 environments of 16 x 16 cells
+ * and 8 agents, 47661 of 8 x 8 cells and 2 agents) returns MG_EINVAL and mg_last_error(NULL) says how many
+ * do.  Fields are taken modulo 16 (heading modulo 4) instead of being checked.  All calls on one GPU share
+ * the buffer: calls that may overlap there (different streams, different threads) race and must be
+ * serialised by the caller; calls on one stream are safe back to back. */
+int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint8_t *agents_dev, const MgOut *out,
+                        void *stream);
 
 /* Debug / parity access to the full state in the reference's layouts (see the top of this file).
  * steps int32[E] = step_count (base.py:350,395); flags uint8[E]: bits 0-5 LockedHallway doors

@@ -19,11 +19,12 @@ MG_OK = 0
 KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
-           "mg_reset", "mg_step", "mg_step_n", "mg_gen_obs", "mg_get_state", "mg_set_state", "mg_stats")
+           "mg_reset", "mg_step", "mg_step_n", "mg_gen_obs", "mg_gen_obs_of_state", "mg_get_state", "mg_set_state",
+           "mg_stats")
 
 
 class MgConfig(ctypes.Structure):
@@ -84,6 +85,7 @@ def lib() -> ctypes.CDLL:
         L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step_n.argtypes = [vp, i32, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_gen_obs.argtypes = [vp, ctypes.POINTER(MgOut), vp]
+        L.mg_gen_obs_of_state.argtypes = [ctypes.POINTER(MgConfig), vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_get_state.argtypes = [vp] * 7
         L.mg_set_state.argtypes = [vp] * 7
         L.mg_stats.argtypes = [vp, vp, vp]

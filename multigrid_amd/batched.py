@@ -31,6 +31,31 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def gen_obs_of_state(spec: dict, grid: torch.Tensor, agents: torch.Tensor, image: Optional[torch.Tensor] = None,
+                     direction: Optional[torch.Tensor] = None, onehot: Optional[torch.Tensor] = None):
+    """``gen_obs`` of states the caller holds (``grid`` uint8 ``[E, W, H, 3]``, ``agents`` uint8 ``[E, A, 8]``, on the
+    GPU) through ``mg_gen_obs_of_state``: no handle, and the library allocates nothing - the outputs are the
+    caller's tensors too.  Limited to what fits the library's fixed 8 MiB staging buffer; calls on one GPU
+    must not overlap."""
+    dev = grid.device
+    for t in (grid, agents, image, direction, onehot):
+        if t is not None and (t.dtype != torch.uint8 or t.device != dev or not t.is_contiguous()):
+            raise ValueError("tensors must be contiguous uint8 tensors on one GPU")
+    e, a, v = int(grid.shape[0]), int(spec["num_agents"]), int(spec["view_size"])
+    w, h = int(spec["width"]), int(spec["height"])
+    if tuple(grid.shape) != (e, w, h, 3) or tuple(agents.shape) != (e, a, 8):
+        raise ValueError(f"bad state shapes {tuple(grid.shape)} {tuple(agents.shape)}")
+    for t, shape in ((image, (e, a, v, v, 3)), (direction, (e, a)), (onehot, (e, a, v, v, _lib.ONE_HOT_DIM))):
+        if t is not None and tuple(t.shape) != shape:
+            raise ValueError(f"expected an output of shape {shape}, got {tuple(t.shape)}")
+    cfg = MgConfig(width=w, height=h, num_agents=a, view_size=v, see_through_walls=int(bool(spec["see_through_walls"])),
+                   num_envs=e, device=dev.index or 0, max_steps=1)
+    p = lambda t: None if t is None else t.data_ptr()
+    mo = MgOut(p(image), p(direction), None, None, None, p(onehot))
+    check(_lib.lib().mg_gen_obs_of_state(ctypes.byref(cfg), _ptr(grid), _ptr(agents), ctypes.byref(mo),
+                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
 class BatchedMultiGrid:
     """``spec`` is a dict with the keys of ``MgConfig`` up to ``num_rooms`` (see include/mgrid.h)."""
 

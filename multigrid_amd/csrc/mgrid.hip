@@ -41,7 +41,16 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "mgrid.h"
+
+// Device memory of mg_gen_obs_of_state(), the one entry point that must not allocate: the packed copy of the
+// caller's state lives here instead of in buffers of a handle.  Every GPU the library runs on holds its own
+// copy of this array until the process ends; host code reaches it only through the per-device address that
+// hipGetSymbolAddress returns (scratch_for_device()), never through the name.
+constexpr size_t MG_SCRATCH_BYTES = 8u << 20;
+static __device__ __align__(256) uint8_t scratch[MG_SCRATCH_BYTES];
 
 namespace {
 
@@ -1780,6 +1789,33 @@ __global__ void mg_validate_state_kernel(KParams p, const uint8_t *grid, const u
     if (n) atomicAdd(bad, n);
 }
 
+// A state in the reference's layouts -> the packed formats, for mg_gen_obs_of_state(): every byte of the
+// environments' header blocks and grids is written (whatever an earlier call left there is gone), fields are
+// taken modulo 16.
+__global__ void mg_pack_state_kernel(KParams p, const uint8_t *grid, const uint8_t *agents) {
+    const int cells = p.W() * p.H(), slots = p.GS / 2;
+    const size_t n = static_cast<size_t>(p.E) * slots;
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t e = i / slots;
+        const int c = static_cast<int>(i - e * slots);
+        uint32_t w = 0;
+        if (c < cells) {
+            const uint8_t *s = grid + (e * cells + c) * 3;
+            w = pack_cell(s[0] & 15u, s[1] & 15u, s[2] & 15u);
+        }
+        reinterpret_cast<uint16_t *>(p.grid + e * p.GS)[c] = static_cast<uint16_t>(w);
+        if (c == 0) {
+            uint8_t *h = p.hdr + e * p.HS;
+            for (int k = 0; k < p.HS; ++k) h[k] = 0;
+            for (int k = 0; k < p.A() * 8; ++k) {
+                const int f = k & 7;
+                h[H_ROWS + k] = agents[e * p.A() * 8 + k] & (f == R_DIR ? 3u : (f >= R_CT ? 15u : 255u));
+            }
+        }
+    }
+}
+
 // Recompute the front cells kept in the header blocks from the grid (after mg_set_state).
 __global__ void mg_refresh_front_kernel(KParams p) {
     const int n = p.E * (p.A() + 2);
@@ -2132,6 +2168,25 @@ int launch_tile(MgEnv *h, const KParams &kp, hipStream_t s) {
         default: return fail(h, MG_EINVAL, "view_size %d not supported", h->cfg.view_size);
     }
     MG_HIP(h, hipGetLastError());
+    return MG_OK;
+}
+
+// Address of this device's copy of `scratch` (looked up once per device, with that device current).
+constexpr int MG_MAX_DEVICES = 64;
+uint8_t *g_scratch_ptr[MG_MAX_DEVICES];
+std::mutex g_scratch_mutex;
+
+int scratch_for_device(int device, uint8_t **ptr) {
+    if (device < 0 || device >= MG_MAX_DEVICES) return fail(nullptr, MG_EINVAL, "device %d not supported (0..%d)", device, MG_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *addr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !addr)
+            return fail(nullptr, MG_EHIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = static_cast<uint8_t *>(addr);
+    }
+    *ptr = g_scratch_ptr[device];
     return MG_OK;
 }
 
@@ -2507,6 +2562,46 @@ int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
     KParams kp = h->kp;
     set_out(kp, out, h->cfg.view_size, h->force_stream);
     return launch_tile<MODE_OBS>(h, kp, static_cast<hipStream_t>(stream));
+}
+
+int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint8_t *agents_dev, const MgOut *out,
+                        void *stream) {
+    if (!cfg || !grid_dev || !agents_dev || !out) return fail(nullptr, MG_EINVAL, "mg_gen_obs_of_state: null argument");
+    if (!out_ok(out)) return fail(nullptr, MG_EINVAL, "mg_gen_obs_of_state: onehot_dev must be 8-byte aligned");
+    MgConfig c = *cfg;  // only the geometry, the view and see_through_walls matter for an observation
+    c.kind = MG_KIND_EMPTY;
+    c.autoreset = MG_AUTORESET_NONE;
+    c.num_rooms = 0;
+    c.max_steps = 1;
+    MgEnv h;  // on the stack: nothing of a handle is allocated
+    int rc = configure(&h, c);
+    if (rc != MG_OK) return rc;
+    KParams kp = h.kp;
+    const size_t hdr_bytes = (static_cast<size_t>(kp.E) * kp.HS + 255) / 256 * 256;
+    const size_t need = hdr_bytes + static_cast<size_t>(kp.E) * kp.GS;
+    if (need > MG_SCRATCH_BYTES)
+        return fail(nullptr, MG_EINVAL,
+                    "mg_gen_obs_of_state: %d environments of %dx%d cells and %d agents need %zu bytes of scratch memory, "
+                    "the fixed buffer holds %zu (at most %zu such environments per call)",
+                    kp.E, kp.W(), kp.H(), kp.A(), need, MG_SCRATCH_BYTES,
+                    (MG_SCRATCH_BYTES - 256) / static_cast<size_t>(kp.HS + kp.GS));
+    hipError_t e = hipSetDevice(c.device);
+    if (e != hipSuccess) return fail(nullptr, MG_EHIP, "mg_gen_obs_of_state: hipSetDevice(%d): %s", c.device, hipGetErrorString(e));
+    uint8_t *base = nullptr;
+    rc = scratch_for_device(c.device, &base);
+    if (rc != MG_OK) return rc;
+    kp.hdr = base;
+    kp.grid = base + hdr_bytes;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = static_cast<size_t>(kp.E) * (kp.GS / 2);
+    hipLaunchKernelGGL(mg_pack_state_kernel, dim3(static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 65535))), dim3(256), 0,
+                       st, kp, grid_dev, agents_dev);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, MG_EHIP, "mg_gen_obs_of_state: %s", hipGetErrorString(e));
+    set_out(kp, out, c.view_size, h.force_stream);
+    rc = launch_tile<MODE_OBS>(&h, kp, st);
+    if (rc != MG_OK) fail(nullptr, rc, "mg_gen_obs_of_state: %s", h.err.c_str());
+    return rc;
 }
 
 int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *meta_dev, int32_t *steps_dev,
