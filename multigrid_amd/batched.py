@@ -220,6 +220,14 @@ class BatchedMultiGrid:
                                       _ptr(flags), self._stream()), self._h)
         return dict(grid=grid, agents=agents, meta=meta, steps=steps, flags=flags)
 
+    def agent_rows(self):
+        """Agent rows uint8 ``[E, A, 8]`` (x y dir terminated carry_type carry_color carry_state color) and step
+        counts int32 ``[E]`` of the current state, without converting the grids."""
+        agents = torch.empty((self.E, self.A, 8), dtype=torch.uint8, device=self.device)
+        steps = torch.empty((self.E,), dtype=torch.int32, device=self.device)
+        check(_lib.lib().mg_get_state(self._h, None, _ptr(agents), None, _ptr(steps), None, self._stream()), self._h)
+        return agents, steps
+
     def set_state(self, grid=None, agents=None, meta=None, steps=None, flags=None):
         e = self.E
         g = None if grid is None else self._dev_u8(grid, (e, self.W, self.H, 3))

@@ -1836,7 +1836,7 @@ __global__ void mg_refresh_front_kernel(KParams p) {
 
 __global__ void mg_get_state_kernel(KParams p, uint8_t *grid, uint8_t *agents, uint8_t *meta, int32_t *steps,
                                     uint8_t *flags) {
-    const int cells = p.W() * p.H();
+    const int cells = grid ? p.W() * p.H() : 1;  // without the grids: one thread per environment
     const size_t n = static_cast<size_t>(p.E) * cells;
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x) {
@@ -2608,7 +2608,7 @@ int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *me
                  uint8_t *flags_dev, void *stream) {
     if (!h) return MG_EINVAL;
     MG_HIP(h, hipSetDevice(h->cfg.device));
-    const size_t n = static_cast<size_t>(h->kp.E) * h->kp.W() * h->kp.H();
+    const size_t n = static_cast<size_t>(h->kp.E) * (grid_dev ? h->kp.W() * h->kp.H() : 1);
     const int blocks = static_cast<int>(std::min<size_t>((n + 255) / 256, 65535));
     hipLaunchKernelGGL(mg_get_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
                        grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);

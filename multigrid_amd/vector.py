@@ -11,6 +11,8 @@ This is the contract of ``gymnasium.vector.SyncVectorEnv`` as the reference uses
 * ``infos["_final_info"]`` marks those environments and ``infos["final_info"][i]`` holds
   ``{"episode": {"r": return, "l": length}}`` for them (``None`` elsewhere).  The same numbers
   are available without leaving the device as ``infos["episode_return"]`` / ``["episode_length"]``.
+  With ``numpy=False`` (the default) ``step`` never waits for the GPU: it returns the mask and those two
+  tensors every step (zeros where no episode ended) and leaves out the per-environment Python objects.
 
 Every array is a PyTorch-ROCm tensor written in place by the HIP kernels (``numpy=True`` converts
 at the boundary like ``SyncVectorEnv`` does).  With ``single_agent=True`` (one agent per
@@ -90,7 +92,15 @@ class MultiGridVectorEnv:
         self._len += 1
         done = out.terminated.bool().all(dim=1) | out.truncated.bool()[:, 0]
         infos = {}
-        if bool(done.any()):
+        if not self.numpy:
+            # everything stays on the GPU and nothing here waits for it: the episode statistics of the
+            # environments that finished (zero elsewhere) and the mask that marks them are returned every step
+            infos["_final_info"] = done
+            infos["episode_return"] = self._view(torch.where(done[:, None], self._ret, torch.zeros_like(self._ret)))
+            infos["episode_length"] = torch.where(done, self._len, torch.zeros_like(self._len))
+            self._ret.masked_fill_(done[:, None], 0.0)
+            self._len.masked_fill_(done, 0)
+        elif bool(done.any()):
             ep_ret = torch.where(done[:, None], self._ret, torch.zeros_like(self._ret))
             ep_len = torch.where(done, self._len, torch.zeros_like(self._len))
             infos["_final_info"] = self._view_mask(done)

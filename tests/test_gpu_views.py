@@ -1,0 +1,132 @@
+"""Batched RLlib / PettingZoo views: the "__all__" keys and the `agents` lists of every environment as device
+tensors, checked against the C oracle, and never waiting for the GPU."""
+import time
+
+import numpy as np
+import pytest
+
+from multigrid_amd import envs, layouts
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(name, agents, e, autoreset, **kw):
+    from multigrid_amd.batched import BatchedMultiGrid
+    from oracle.coracle import BatchOracle
+    spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
+    pool = layouts.make_pool(gen, 64, seed0=3)
+    sim = BatchedMultiGrid(spec, e, device=0, autoreset=autoreset)
+    sim.upload_layouts(pool[0], pool[1], pool[2])
+    return spec, pool, sim, BatchOracle(spec, e)
+
+
+@pytest.mark.parametrize("name,agents,kw", [
+    ("MultiGrid-Empty-5x5-v0", 1, dict(max_steps=90, success_termination_mode="all")),
+    ("MultiGrid-Empty-5x5-v0", 3, dict(max_steps=25, success_termination_mode="all")),
+    ("MultiGrid-BlockedUnlockPickup-v0", 2, dict(max_steps=30)),
+])
+def test_rllib_view_all_keys(name, agents, kw):
+    """terminations["__all__"] / truncations["__all__"] of multigrid/rllib/__init__.py:71-76 for 2500 environments."""
+    import torch
+    from multigrid_amd.views import BatchedRLlibView
+    e = 2500
+    spec, pool, sim, ora = setup(name, agents, e, 0, **kw)
+    view = BatchedRLlibView(sim)
+    rng = np.random.default_rng(8)
+    idx = rng.integers(0, 64, size=e)
+    obs, infos = view.reset(layout_idx=idx)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    assert infos == {} and view.get_agent_ids() == set(range(agents))
+    np.testing.assert_array_equal(obs["image"].cpu().numpy(), ora.gen_obs())
+    seen_all = seen_some = 0
+    for t in range(40 if agents > 1 else 100):
+        actions = rng.integers(0, 7, size=(e, agents)).astype(np.uint8)
+        order = np.argsort(rng.random((e, agents)), axis=1).astype(np.uint8)
+        obs, rew, term, trunc, infos = view.step(torch.as_tensor(actions, device="cuda:0"), torch.as_tensor(order, device="cuda:0"))
+        img, direction, r, tm, tr = ora.step(actions, order)
+        assert all(isinstance(x, torch.Tensor) and x.is_cuda for x in (obs["image"], rew, term["agents"], term["__all__"]))
+        np.testing.assert_array_equal(obs["image"].cpu().numpy(), img)
+        np.testing.assert_array_equal(term["agents"].cpu().numpy(), tm.astype(bool))
+        np.testing.assert_array_equal(term["__all__"].cpu().numpy(), tm.astype(bool).all(axis=1))
+        np.testing.assert_array_equal(trunc["__all__"].cpu().numpy(), tr.astype(bool).all(axis=1))
+        np.testing.assert_allclose(rew.cpu().numpy(), r, rtol=0, atol=1e-6)
+        seen_all += int(tm.all(axis=1).sum())
+        seen_some += int((tm.any(axis=1) & ~tm.all(axis=1)).sum())
+        done = tm.all(axis=1) | tr.all(axis=1)
+        if done.any():  # the caller resets, as with the reference
+            ids = np.nonzero(done)[0]
+            new = rng.integers(0, 64, size=e)
+            ora.load(ids, pool[0][new[ids]], pool[1][new[ids]], pool[2][new[ids]])
+            view.reset(layout_idx=new, mask=done.astype(np.uint8))
+    assert seen_all > 0 or agents > 1  # a lone agent does reach the goal within 90 steps somewhere
+    assert seen_some > 0 or "Empty" not in name or agents == 1  # some but not all terminated: "__all__" must stay False
+    sim.close()
+
+
+def test_parallel_view_agents_mask():
+    """PettingZooWrapper.agents (multigrid/pettingzoo/__init__.py:48-52) for every environment: the agents whose own
+    terminated flag is clear, none once the environment is done."""
+    import torch
+    from multigrid_amd.views import BatchedParallelView
+    e, agents = 3000, 4
+    spec, pool, sim, ora = setup("MultiGrid-Empty-5x5-v0", agents, e, 0, max_steps=20, success_termination_mode="all",
+                                 failure_termination_mode="all")
+    view = BatchedParallelView(sim)
+    assert view.possible_agents == list(range(agents))
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, 64, size=e)
+    view.reset(layout_idx=idx)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    partial = 0
+    for t in range(24):  # four steps beyond truncation: the reference lists no agents then
+        actions = rng.integers(0, 7, size=(e, agents)).astype(np.uint8)
+        order = np.argsort(rng.random((e, agents)), axis=1).astype(np.uint8)
+        view.step(actions, order)
+        ora.step(actions, order)
+        term = ora.agents[:, :, 3].astype(bool)
+        done = (ora.steps >= spec["max_steps"]) | term.all(axis=1)
+        expect = ~term & ~done[:, None]
+        mask = view.agents_mask
+        assert isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dtype == torch.bool
+        np.testing.assert_array_equal(mask.cpu().numpy(), expect, err_msg=f"step {t}")
+        np.testing.assert_array_equal(view.is_done().cpu().numpy(), done)
+        partial += int((expect.any(axis=1) & ~expect.all(axis=1)).sum())
+    assert partial > 0 and not expect.any()
+    sim.close()
+
+
+def test_views_and_vector_env_never_wait_for_the_gpu():
+    """A step of the batched views and of the tensor-mode vector environment only enqueues work: torch raises on any
+    synchronising call while they run, and enqueueing 100 steps returns long before the GPU has finished them."""
+    import torch
+    from multigrid_amd.vector import MultiGridVectorEnv
+    from multigrid_amd.views import BatchedParallelView, BatchedRLlibView
+    e, agents = 65536, 8
+    venv = MultiGridVectorEnv("MultiGrid-Empty-16x16-v0", e, agents=agents, device=0, num_layouts=16, seed=1,
+                              one_hot=True, agent_view_size=7)
+    venv.reset()
+    spec, pool, sim, _ = setup("MultiGrid-Empty-16x16-v0", agents, e, 2)
+    rl, pz = BatchedRLlibView(sim), BatchedParallelView(sim)
+    rl.reset()
+    acts = torch.randint(0, 7, (8, e, agents), device="cuda:0", dtype=torch.uint8)
+    for t in range(5):
+        venv.step(acts[t])
+        rl.step(acts[t])
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        t0 = time.perf_counter()
+        for t in range(100):
+            obs, rew, term, trunc, infos = venv.step(acts[t % 8])
+            assert infos["_final_info"].is_cuda and infos["episode_return"].is_cuda and infos["episode_length"].is_cuda
+        enqueue = time.perf_counter() - t0
+        for t in range(20):
+            obs, rew, term, trunc, _ = rl.step(acts[t % 8])
+            mask = pz.agents_mask
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    assert enqueue < 0.7 * total, (enqueue, total)
+    venv.close()
+    sim.close()
