@@ -112,7 +112,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
         else:
             assert n % T == 0
             for t in range(n // T):
-                env.step_n(actions[(t % 2) * T:(t % 2 + 1) * T], out=outn, fused=True)
+                env.step_n(actions[(t % 2) * T:(t % 2 + 1) * T], out=outn)
 
     run(warmup if T == 1 else max(T, warmup // T * T))
     graphed = None
@@ -504,10 +504,10 @@ def main(argv=None):
         # launch-bound batches: the same steps replayed from a HIP graph, and fused into one launch per T steps
         for cid in (2, 3, 4):
             add(cid, CONFIGS[cid][2], "HIP graph of 16 launches", 400, 48, graph=True)
-        if hasattr(__import__("multigrid_amd._lib", fromlist=["x"]), "HAVE_FUSED_STEP_N"):
-            for cid in (2, 3, 4):
-                for Tx in (8, 64):
-                    add(cid, CONFIGS[cid][2], f"fused launch of {Tx} steps", 384, 64, steps_per_launch=Tx)
+        for cid in (2, 3, 4, 5):
+            for Tx in (8, 64):
+                add(cid, CONFIGS[cid][2], f"one launch per {Tx} steps (mg_step_n)", 384 if cid != 5 else 128, 64,
+                    steps_per_launch=Tx)
         line["other_configs"] = extra
         line["config1_one_env"] = latency_one_env(args)
     if rank == 0 and world == 1 and not args.no_cpu:

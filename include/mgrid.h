@@ -145,7 +145,10 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
 int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out,
             void *stream);
 
-/* `num_steps` consecutive mg_step calls queued by one call (a rollout whose actions are known up
+/* `num_steps` consecutive steps by one call; for num_steps > 1 and no one-hot output they are taken by ONE kernel
+ * launch that keeps the environments' state in on-chip memory between the steps (same results as
+ * `num_steps` mg_step calls, less memory traffic and no launch gaps).  It stands for `num_steps`
+ * consecutive mg_step calls (a rollout whose actions are known up
  * front, e.g. the random-action loop of multigrid/scripts/train_ppo_cleanrl.py:517-529 with the policy
  * replaced by a table).  Every array gains a leading [num_steps] dimension: actions_dev
  * uint8[T][E][A], order_dev uint8[T][E][A] or NULL, and each non-NULL pointer of `out`

@@ -39,6 +39,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <mutex>
@@ -126,6 +127,7 @@ struct KParams {
     uint32_t env_offset;
     uint64_t seed;
     uint32_t serial;  // reset launches so far (0: the first reset starts the episode counters)
+    int T;            // steps taken by one launch of the multi-step kernel (mg_step_n); inputs and outputs are [T][E][A]...
     // state
     uint8_t *hdr;
     uint8_t *grid;
@@ -1252,12 +1254,18 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
 // the whole launch; grids are brought in NE environments ("sub-tile", NE * A <= 64 agent lanes)
 // at a time for the observation passes.
 
-template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH>
+// MULTI: the launch takes p.T consecutive steps (mg_step_n).  Header blocks AND the grids of all ET environments
+// then stay in LDS from the first step to the last; per step only actions come in and observations, rewards and
+// flags go out (plus the few grid cells a step changes, which still go to HBM at once, and restarts from the pool).
+template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false>
 #ifndef MG_KERNEL_ATTR
 #define MG_KERNEL_ATTR
 #endif
-__global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParams p) {
+__global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParams p0) {
     extern __shared__ __align__(16) uint8_t lds[];
+    static_assert(!MULTI || (MODE == MODE_STEP && !OH), "the multi-step kernel steps and writes compact images");
+    // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
+    typename std::conditional<MULTI, KParams, const KParams &>::type p = p0;
     constexpr int IMG = 3 * V * V;  // bytes per agent image
     const int lane = threadIdx.x;
     const int A = p.A(), NE = p.NE(), NC = A + 2;
@@ -1337,6 +1345,27 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
             }
         }
     };
+    // multi-step kernel: every grid of the tile has its own place in LDS (environment s at s * (GS + 16))
+    auto load_all_grids = [&]() {
+        const int n16_ = net * per;
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0) * p.GS);
+        uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
+#pragma unroll 1
+        for (int i = lane; i < n16_; i += 64) dg_[i + udiv(i, p.magic_per)] = src_[i];
+    };
+    auto patch_all_grids = [&]() {  // environments restarted since the last patch: their grid comes from the pool
+        if (__ballot(lane < net && lsrc[lane] >= 0)) {
+            const int n16_ = net * per;
+            uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
+#pragma unroll 1
+            for (int i = lane; i < n16_; i += 64) {
+                const int sub = udiv(i, p.magic_per);
+                const int src = lsrc[sub];
+                if (src >= 0)
+                    dg_[i + sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
+            }
+        }
+    };
 #undef MG_ISSUE1
 #undef MG_COMMIT1
 #undef MG_EACH
@@ -1364,6 +1393,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                 if (go) ow = *reinterpret_cast<const uint32_t *>(go + 4 * lane);
             }
         }
+        if (MULTI) load_all_grids(); else
         if (passes && MODE != MODE_RESET) issue(0);
         wave_sync();
         if (lane < nh) dh[lane] = hb0;
@@ -1423,6 +1453,22 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
     unsigned long long ta0 = 0, ta1 = 0, ta2 = 0;
     MG_TICK(ta0);
 #endif
+    const int nsteps = MULTI ? p.T : 1;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {  // one pass unless MULTI
+    if (MULTI && t > 0) {
+        // the next step's actions and order (p.actions / p.order have moved on to its slice)
+        wave_sync();
+        const uint8_t *ga = p.actions + static_cast<size_t>(e0) * A;
+        const uint8_t *go = p.order ? p.order + static_cast<size_t>(e0) * A : nullptr;
+#pragma unroll 1
+        for (int b = lane; b < nag; b += 64) {
+            lds[p.o.act + b] = ga[b];
+            if (go) lds[p.o.ord + b] = go[b];
+        }
+        if (lane < ET) lsrc[lane] = -1;
+        wave_sync();
+    }
     if (MODE == MODE_STEP) {
         if (A >= PARALLEL_ACT_MIN_AGENTS) {
 #pragma unroll 1
@@ -1480,15 +1526,20 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
     MG_STAMP(3);
     // ---- observe: NE environments at a time -------------------------------------------------------------
     if (passes) {
-        if (MODE == MODE_RESET) issue(0);
-        commit(0);
+        if (MULTI) {
+            patch_all_grids();
+        } else {
+            if (MODE == MODE_RESET) issue(0);
+            commit(0);
+        }
         wave_sync();
         for (int s0 = 0; s0 < net; s0 += NE) {
             const int ns = min(NE, net - s0);
             const int np = ns * A;
             const uint64_t sub_mask = (active_mask >> s0) & ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
             const bool all_active = sub_mask == ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
-            const bool has_next = s0 + NE < net;
+            const bool has_next = !MULTI && s0 + NE < net;
+            const int gslot0 = MULTI ? s0 : 0;  // where the sub-tile's grids start in LDS
 #ifdef MGRID_EXPERIMENT
             unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
             MG_TICK(tk0);
@@ -1496,12 +1547,12 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
             const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
-            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + my_slot * (p.GS + 16));
+            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + my_slot) * (p.GS + 16));
             if (MODE == MODE_STEP) {
                 // cells changed by this step, replayed in order (one lane per environment)
                 if (lane < ns && ((sub_mask >> lane) & 1)) {
                     const uint32_t *log = reinterpret_cast<const uint32_t *>(lds + p.o.log) + (s0 + lane) * A;
-                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + lane * (p.GS + 16));
+                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
                     const int n = lds[p.o.flag + 4 * (s0 + lane) + 2];
                     for (int j = 0; j < n; ++j) {
                         const uint32_t e = log[j];
@@ -1527,7 +1578,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                 if (p.kind() == MG_KIND_REDBLUEDOORS && lane < ns && ((sub_mask >> lane) & 1)) {
                     uint8_t *h = lds + p.o.hdr + (s0 + lane) * p.HS;
                     const uint32_t meta = *reinterpret_cast<const uint32_t *>(h + H_META);
-                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + lane * (p.GS + 16));
+                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
                     const uint32_t last = static_cast<uint32_t>(p.W() * p.H() - 1);
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A] = g[min((meta & 0xFF) * p.H() + ((meta >> 8) & 0xFF), last)];
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A + 1] = g[min(((meta >> 16) & 0xFF) * p.H() + (meta >> 24), last)];
@@ -1541,11 +1592,12 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 8))
 #endif
+            bool draw = false;  // this lane's agent is drawn at cell `ci`, which held `under`
+            uint32_t ci = 0, under = 0;
             if (want_img && A > 1) {
                 // LDS writes of one wavefront land in program order, so drawing the agents index by index
                 // leaves the highest one on a shared cell without looking at the other agents at all
-                bool draw = false;
-                uint32_t ci = 0, val = 0;
+                uint32_t val = 0;
                 if (mine && !my_gone) {
                     const uint2 r = my_row;
                     const unsigned x = r.x & 0xFF, y = (r.x >> 8) & 0xFF;
@@ -1553,6 +1605,9 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                     ci = x * p.H() + y;
                     val = T_AGENT | (((r.x >> 16) & 0xFF) << 4) | ((r.y >> 24) << 8);
                 }
+                // the multi-step kernel keeps its grids: every lane notes what lies under its agent before the
+                // first agent is drawn, and puts it back once the views have been taken
+                if (MULTI && draw) under = my_grid[ci];
 #pragma unroll 1
                 for (int k = 0; k < A; ++k) {
                     if (draw && my_agent == k) my_grid[ci] = static_cast<uint16_t>(val);
@@ -1570,8 +1625,12 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
             if (!(p.dbg & 1))
 #endif
             if (want_img && mine)
-                observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + my_slot * (p.GS + 16), px);
+                observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + (gslot0 + my_slot) * (p.GS + 16), px);
             wave_sync();
+            if (MULTI) {
+                if (draw) my_grid[ci] = static_cast<uint16_t>(under);
+                wave_sync();
+            }
             // The next sub-tile's grids set out now, travel while this sub-tile's images are stored and
             // replace this sub-tile's grids in LDS at the end of the pass; they occupy registers only
             // while the observation's own are free.
@@ -1724,11 +1783,28 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
                 const int env = e0 + s;
                 const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HS + H_EPISODE) + 1u;
                 wave_sync();
-                reload_env(p, lds, s, env, pick_layout(p, env, episode), episode, lane);
+                const int layout = pick_layout(p, env, episode);
+                reload_env(p, lds, s, env, layout, episode, lane);
+                if (MULTI && lane == 0) lsrc[s] = layout;
             }
             wave_sync();
+            if (MULTI) {  // the grids kept in LDS follow
+                patch_all_grids();
+                wave_sync();
+            }
         }
     }
+    if constexpr (MULTI) {  // on to the next step's slices of the inputs and outputs
+        const size_t ea = static_cast<size_t>(p.E) * A;
+        p.actions += ea;
+        if (p.order) p.order += ea;
+        if (p.image) p.image += ea * IMG;
+        if (p.direction) p.direction += ea;
+        if (p.reward) p.reward += ea;
+        if (p.terminated) p.terminated += ea;
+        if (p.truncated) p.truncated += ea;
+    }
+    }  // steps of this launch
     if (MODE != MODE_OBS) {
         // header blocks back to HBM (reset mode: only the environments that were reset)
         uint4 *dh = reinterpret_cast<uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
@@ -2094,6 +2170,10 @@ struct MgEnv {
     KParams kp{};
     size_t lds_bytes = 0;
     int num_tiles = 0;
+    // the multi-step kernel (mg_step_n) keeps every grid of a tile in LDS and stages images beside them
+    LdsMap o_multi{};
+    size_t lds_multi = 0;  // 0: the configuration does not fit, mg_step_n falls back to one launch per step
+    bool multi_enabled = true;
     uint8_t *hdr = nullptr, *grid = nullptr, *pool_hdr = nullptr, *pool_grid = nullptr;
     int64_t *stats = nullptr;
     int num_layouts = 0;
@@ -2129,25 +2209,39 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int V, int MODE, bool WALLED, bool OH>
+template <int V, int MODE, bool WALLED, bool OH, bool MULTI = false>
 void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
     KParams kp = kp_in;
-    kp.o.oh = static_cast<int>(h->lds_bytes);  // the exchange buffer follows everything else
-    const size_t lds = h->lds_bytes + (OH ? OH_XCHG_BYTES : 0);
+    size_t lds = h->lds_bytes + (OH ? OH_XCHG_BYTES : 0);
+    if (MULTI) {
+        kp.o = h->o_multi;
+        lds = h->lds_multi;
+    } else {
+        kp.o.oh = static_cast<int>(h->lds_bytes);  // the exchange buffer follows everything else
+    }
     const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
     if (see && small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH>), grid, block, lds, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH, MULTI>), grid, block, lds, s, kp);
     else if (see)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED, OH>), grid, block, lds, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED, OH, MULTI>), grid, block, lds, s, kp);
     else if (small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH>), grid, block, lds, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH, MULTI>), grid, block, lds, s, kp);
     else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED, OH>), grid, block, lds, s, kp);
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED, OH, MULTI>), grid, block, lds, s, kp);
 }
 
 template <int V, int MODE>
 void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
+    if constexpr (MODE == MODE_STEP) {
+        if (kp.T > 1) {  // mg_step_n: one launch for T steps (never with one-hot images)
+            if (kp.walled())
+                launch_vmw<V, MODE, true, false, true>(h, kp, s);
+            else
+                launch_vmw<V, MODE, false, false, true>(h, kp, s);
+            return;
+        }
+    }
     // launches that also write one-hot images are bound by those stores; they share the general-border code
     if (kp.onehot)
         launch_vmw<V, MODE, false, true>(h, kp, s);
@@ -2258,7 +2352,7 @@ int configure(MgEnv *h, const MgConfig &c) {
     // Small batches get small tiles: the launch then has enough wavefronts to cover the chip and
     // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
-    auto lds_for = [&](int ne, int g) {
+    auto lds_for = [&](int ne, int g, bool multi = false) {
         const int et = ne * g, np = ne * c.num_agents;
         int o = 0;
         auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
@@ -2272,6 +2366,12 @@ int configure(MgEnv *h, const MgConfig &c) {
         kp.o.flag = take(4 * et);
         kp.o.R = take(8 * et);
         kp.o.src = take(4 * et);
+        if (multi) {  // every grid of the tile stays; images are staged beside them
+            kp.o.grid = take(et * (kp.GS + 16));
+            kp.o.stage = take(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np));
+            kp.o.img = kp.o.stage;  // act_lanes() scratch: idle while images are staged
+            return o;
+        }
         kp.o.grid = take(ne * (kp.GS + 16));  // 16 bytes between grids spread them over the LDS banks
         const int grids = round_up(ne * (kp.GS + 16), 16);
         kp.o.stage = kp.o.grid;  // images are staged over the grids of the sub-tile they were made from
@@ -2298,6 +2398,13 @@ int configure(MgEnv *h, const MgConfig &c) {
             ne = a;
             g = b;
         }
+    }
+    {  // the same tile shape for the multi-step kernel, where it fits
+        const int need = lds_for(ne, g, true);
+        h->o_multi = kp.o;
+        h->o_multi.oh = 0;
+        h->lds_multi = need <= 64 * 1024 ? static_cast<size_t>(need) : 0;
+        if (const char *ev = getenv("MGRID_MULTI_STEP")) h->multi_enabled = atoi(ev) != 0;  // tuning / test override
     }
     h->lds_bytes = static_cast<size_t>(lds_for(ne, g));
 #ifdef MGRID_EXPERIMENT
@@ -2521,6 +2628,7 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
     kp.actions = actions_dev;
     kp.order = order_dev;
     kp.serial = h->step_serial;
+    kp.T = 1;
     set_out(kp, out, h->cfg.view_size, h->force_stream);
     const int rc = launch_tile<MODE_STEP>(h, kp, static_cast<hipStream_t>(stream));
     if (rc != MG_OK) return rc;
@@ -2533,7 +2641,27 @@ int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const u
               void *stream) {
     if (!h) return MG_EINVAL;
     if (num_steps < 1) return fail(h, MG_EINVAL, "mg_step_n: num_steps must be positive");
-    // one launch per step, all queued on the stream by this one call; step t reads slice t of the
+    if (num_steps > 1 && h->lds_multi && h->multi_enabled && !(out && out->onehot_dev)) {
+        // ONE launch takes all the steps: header blocks and grids stay in LDS in between, per step only the
+        // actions come in and the observations, rewards and flags go out
+        if (!actions_dev) return fail(h, MG_EINVAL, "mg_step_n: actions_dev is null");
+        if (!h->reset_done) return fail(h, MG_ESTATE, "mg_step_n: call mg_reset (or mg_set_state) first");
+        if (h->cfg.autoreset != MG_AUTORESET_NONE && h->num_layouts < 1)
+            return fail(h, MG_ESTATE, "mg_step_n: autoreset needs uploaded layouts");
+        MG_HIP(h, hipSetDevice(h->cfg.device));
+        KParams kp = h->kp;
+        kp.actions = actions_dev;
+        kp.order = order_dev;
+        kp.serial = h->step_serial;
+        kp.T = num_steps;
+        set_out(kp, out, h->cfg.view_size, h->force_stream);
+        const int rc = launch_tile<MODE_STEP>(h, kp, static_cast<hipStream_t>(stream));
+        if (rc != MG_OK) return rc;
+        h->step_serial += static_cast<uint32_t>(num_steps);
+        h->launches += num_steps;
+        return MG_OK;
+    }
+    // otherwise one launch per step, all queued on the stream by this one call; step t reads slice t of the
     // inputs and writes slice t of every output
     const size_t per = static_cast<size_t>(h->kp.E) * h->kp.A();
     const size_t img = 3u * h->cfg.view_size * h->cfg.view_size;
