@@ -1261,7 +1261,15 @@ template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MUL
 #ifndef MG_KERNEL_ATTR
 #define MG_KERNEL_ATTR
 #endif
-__global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParams p0) {
+// tuning builds: wavefronts per SIMD the register allocation must leave room for (single-step / multi-step kernels)
+#ifndef MG_WAVES_SINGLE
+#define MG_WAVES_SINGLE 1
+#endif
+#ifndef MG_WAVES_MULTI
+#define MG_WAVES_MULTI 1
+#endif
+__global__ __launch_bounds__(64) MG_KERNEL_ATTR
+__attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))) void mg_tile_kernel(const KParams p0) {
     extern __shared__ __align__(16) uint8_t lds[];
     static_assert(!MULTI || (MODE == MODE_STEP && !OH), "the multi-step kernel steps and writes compact images");
     // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
@@ -1453,9 +1461,8 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
     unsigned long long ta0 = 0, ta1 = 0, ta2 = 0;
     MG_TICK(ta0);
 #endif
-    const int nsteps = MULTI ? p.T : 1;
-#pragma unroll 1
-    for (int t = 0; t < nsteps; ++t) {  // one pass unless MULTI
+    int t = 0;
+    do {  // one pass unless MULTI
     if (MULTI && t > 0) {
         // the next step's actions and order (p.actions / p.order have moved on to its slice)
         wave_sync();
@@ -1804,7 +1811,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR void mg_tile_kernel(const KParam
         if (p.terminated) p.terminated += ea;
         if (p.truncated) p.truncated += ea;
     }
-    }  // steps of this launch
+    } while (MULTI && ++t < p.T);  // steps of this launch
     if (MODE != MODE_OBS) {
         // header blocks back to HBM (reset mode: only the environments that were reset)
         uint4 *dh = reinterpret_cast<uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
