@@ -20,7 +20,9 @@ SPEC_FIELDS = ("kind", "width", "height", "num_agents", "view_size", "max_steps"
 
 
 class CSpec(ctypes.Structure):
-    _fields_ = [(name, ctypes.c_int32) for name in SPEC_FIELDS]
+    _fields_ = [(name, ctypes.c_int32) for name in SPEC_FIELDS] + [
+        ("death_match", ctypes.c_int32), ("per_agent_outputs", ctypes.c_int32),
+        ("reward_schemes", (ctypes.c_double * 4) * 8)]
 
 
 def build(force: bool = False) -> str:
@@ -55,6 +57,11 @@ class BatchOracle:
     def __init__(self, spec: dict, num_envs: int):
         self.spec = dict(spec)
         self.cspec = CSpec(**{k: int(spec[k]) for k in SPEC_FIELDS})
+        self.cspec.death_match = int(bool(spec.get("death_match", False)))
+        self.cspec.per_agent_outputs = int(bool(spec.get("per_agent_outputs", True)))
+        for i, row in enumerate(spec.get("reward_schemes") or []):
+            for j, v in enumerate(row):
+                self.cspec.reward_schemes[i][j] = float(v)
         self.E = int(num_envs)
         w, h, a, v = (int(spec[k]) for k in ("width", "height", "num_agents", "view_size"))
         self.A, self.V = a, v

@@ -21,6 +21,11 @@
  *                                colour (locked_hallway.py:190,204-205); bit 7: the blue
  *                                Door object was re-closed after a failure while its grid
  *                                cell still reads open (redbluedoors.py:185)
+ * CompetativeRedBlueDoorEnvV3 (multigrid/envs/competative_red_blue_door.py) keeps what the arrays
+ * do not show in the same two places: flags bit 0 / 1 = the red / blue key OBJECT is "picked up"
+ * (:434-435) while the agent row still holds the copy made at pickup time; bit 2 / 3 = the red / blue
+ * door's cell was cleared under an eliminated agent (:503), the orphaned object stays open;
+ * meta[0] / meta[1] = how often the red / blue ball's discount factor has been squared (:454).
  */
 #include <stdint.h>
 #include <string.h>
@@ -28,7 +33,10 @@
 enum { T_UNSEEN, T_EMPTY, T_WALL, T_FLOOR, T_DOOR, T_KEY, T_BALL, T_BOX, T_GOAL, T_LAVA, T_AGENT };
 enum { S_OPEN, S_CLOSED, S_LOCKED };
 enum { A_LEFT, A_RIGHT, A_FORWARD, A_PICKUP, A_DROP, A_TOGGLE, A_DONE };
-enum { K_EMPTY, K_REDBLUEDOORS, K_BLOCKEDUNLOCKPICKUP, K_LOCKEDHALLWAY };
+enum { K_EMPTY, K_REDBLUEDOORS, K_BLOCKEDUNLOCKPICKUP, K_LOCKEDHALLWAY, K_COMPETITIVE };
+enum { S_PICKEDUP = 3, S_AVAILABLE = 4 };       /* multigrid/core/constants.py:91-102 */
+enum { C_RED = 0, C_BLUE = 2 };                 /* multigrid/core/constants.py:50-59 */
+enum { RS_ELIMINATED, RS_KEY, RS_BALL, RS_INVALID }; /* reward_schemes columns, multigrid/envs/__init__.py:100-108 */
 enum { AX, AY, ADIR, ATERM, ACT, ACC, ACS, ACOLOR };
 #define FLAG_BLUE_STALE 0x80
 #define MAX_AGENTS 64
@@ -38,6 +46,9 @@ typedef struct {
     int32_t kind, width, height, num_agents, view_size, max_steps;
     int32_t see_through_walls, allow_agent_overlap, joint_reward;
     int32_t success_any, failure_any, num_rooms;
+    /* CompetativeRedBlueDoorEnvV3 only (at most 8 agents) */
+    int32_t death_match, per_agent_outputs;
+    double reward_schemes[8][4];
 } mgo_spec;
 
 /* DIR_TO_VEC, multigrid/core/constants.py:20-29 */
@@ -131,7 +142,7 @@ void mgo_gen_obs(const mgo_spec *sp, int64_t E, const uint8_t *grid, const uint8
 typedef struct {
     const mgo_spec *sp;
     uint8_t *grid, *agents;
-    const uint8_t *meta;
+    uint8_t *meta;
     int32_t steps;
     uint8_t flags;
     double *reward;
@@ -190,6 +201,104 @@ static void on_failure(env_t *e, int i, uint8_t *term_out) {
     }
 }
 
+/* ---- CompetativeRedBlueDoorEnvV3 ------------------------------------------------- */
+
+/* state of the OBJECT agent i carries: a key that has paid its pickup reward is State.pickedup
+ * (competative_red_blue_door.py:434-435), whatever the copy in the agent row says */
+static int carried_state(const env_t *e, int i) {
+    const uint8_t *ag = e->agents + 8 * i;
+    if (ag[ACT] == T_KEY && (ag[ACC] == C_RED || ag[ACC] == C_BLUE) && (e->flags & (1u << (ag[ACC] / 2)))) return S_PICKEDUP;
+    return ag[ACS];
+}
+
+/* door positions of _gen_grid, :201-211 */
+static void comp_door(const env_t *e, int which, int *x, int *y) {
+    const int W = e->sp->width, H = e->sp->height;
+    if (which == 0) { *x = W / 4; *y = H - 2; } else { *x = W / 4 + W / 2 - 1; *y = 1; }
+}
+
+/* self.red_door.is_open / self.blue_door.is_open (:485): the door OBJECT, open for good once orphaned */
+static int comp_door_open(env_t *e, int which) {
+    int x, y;
+    if (e->flags & (4u << which)) return 1;
+    comp_door(e, which, &x, &y);
+    return cell(e, x, y)[0] == T_DOOR && cell(e, x, y)[2] == S_OPEN;
+}
+
+static void on_success(env_t *e, int i, uint8_t *term_out);
+static void on_failure(env_t *e, int i, uint8_t *term_out);
+
+/* _handle_steps, :475-523 */
+static void comp_handle_steps(env_t *e, int i, int act, uint8_t *term_out) {
+    const mgo_spec *sp = e->sp;
+    const int A = sp->num_agents;
+    uint8_t *ag = e->agents + 8 * i;
+    if (act != A_TOGGLE) return;
+    const int fx = ag[AX] + DX[ag[ADIR]], fy = ag[AY] + DY[ag[ADIR]];
+    int victim = -1;
+    for (int k = 0; k < A; ++k) { /* :479-481 */
+        const uint8_t *o = e->agents + 8 * k;
+        if (o[AX] == fx && o[AY] == fy && o[ACOLOR] != ag[ACOLOR]) victim = k;
+    }
+    if (victim < 0) {
+        for (int which = 0; which < 2; ++which) { /* :484 object identity */
+            int dx, dy;
+            comp_door(e, which, &dx, &dy);
+            if (fx != dx || fy != dy || cell(e, dx, dy)[0] != T_DOOR || (e->flags & (4u << which))) continue;
+            if ((comp_door_open(e, 0) || comp_door_open(e, 1)) && cell(e, dx, dy)[1] == ag[ACOLOR])
+                for (int k = 0; k < A; ++k) /* :487-492 */
+                    if (e->agents[8 * k + ACOLOR] == ag[ACOLOR] && !e->agents[8 * k + ATERM]) on_success(e, k, term_out);
+        }
+    } else if (sp->death_match) { /* :498-523 */
+        uint8_t *v = e->agents + 8 * victim;
+        on_failure(e, victim, NULL);
+        for (int which = 0; which < 2; ++which) {
+            int dx, dy;
+            comp_door(e, which, &dx, &dy);
+            if (v[AX] == dx && v[AY] == dy && cell(e, dx, dy)[0] == T_DOOR) e->flags |= (uint8_t)(4u << which);
+        }
+        uint8_t *c = cell(e, v[AX], v[AY]); /* :503 */
+        c[0] = T_EMPTY; c[1] = 0; c[2] = 0;
+        if (v[ACOLOR] == C_BLUE) { v[AX] = 13; v[AY] = 2; } else { v[AX] = 2; v[AY] = 2; } /* :504-506 */
+        e->reward[i] += sp->reward_schemes[i][RS_ELIMINATED];
+        e->reward[victim] -= 1;
+        int all_gone = 1; /* :511-513 */
+        for (int k = 0; k < A; ++k)
+            if (e->agents[8 * k + ACOLOR] != ag[ACOLOR] && !e->agents[8 * k + ATERM]) all_gone = 0;
+        if (all_gone)
+            for (int k = 0; k < A; ++k)
+                if (e->agents[8 * k + ACOLOR] == ag[ACOLOR] && !e->agents[8 * k + ATERM]) on_success(e, k, term_out);
+    }
+}
+
+/* _default_extra_action_handle_steps, :425-472 */
+static void comp_pickup_rewards(env_t *e, int i, int act) {
+    const mgo_spec *sp = e->sp;
+    const uint8_t *ag = e->agents + 8 * i;
+    if (act != A_PICKUP) return;
+    const double *rs = sp->reward_schemes[i];
+    if (ag[ACT] == T_KEY && carried_state(e, i) == S_AVAILABLE && ag[ACC] == ag[ACOLOR]) { /* :428-436 */
+        if (ag[ACC] == C_RED || ag[ACC] == C_BLUE) e->flags |= (uint8_t)(1u << (ag[ACC] / 2));
+        e->reward[i] += rs[RS_KEY];
+        return;
+    }
+    if (ag[ACT] == T_BALL && ag[ACC] != ag[ACOLOR] && (ag[ACC] == C_RED || ag[ACC] == C_BLUE)) { /* :445-454 */
+        int rx, ry, bx, by;
+        comp_door(e, 0, &rx, &ry);
+        comp_door(e, 1, &bx, &by);
+        const int ix = ag[ACC] == C_RED ? bx - 1 : rx + 1, iy = ag[ACC] == C_RED ? by : ry; /* init_pos, :230-232 */
+        if (ag[AX] + DX[ag[ADIR]] == ix && ag[AY] + DY[ag[ADIR]] == iy) {
+            const int slot = ag[ACC] / 2;
+            double d = 0.9; /* Ball.__new__ default, world_object.py:583 */
+            for (int n = 0; n < e->meta[slot]; ++n) d *= d;
+            e->reward[i] += rs[RS_BALL] * d;
+            if (e->meta[slot] < 255) e->meta[slot]++;
+            return;
+        }
+    }
+    e->reward[i] -= rs[RS_INVALID]; /* :470-472 */
+}
+
 /* handle_actions, base.py:440-533 */
 static void handle_actions(env_t *e, const uint8_t *actions, const uint8_t *order) {
     const mgo_spec *sp = e->sp;
@@ -214,13 +323,18 @@ static void handle_actions(env_t *e, const uint8_t *actions, const uint8_t *orde
             if (t == T_GOAL) on_success(e, i, NULL);
             if (t == T_LAVA) on_failure(e, i, NULL);
         } else if (act == A_PICKUP) { /* base.py:497-504 */
-            if ((t == T_KEY || t == T_BALL || t == T_BOX) && ag[ACT] == T_EMPTY) {
+            int ok = t == T_KEY || t == T_BALL || t == T_BOX;
+            if (sp->kind == K_COMPETITIVE) /* competative_red_blue_door.py:573-577: own key, the others' ball */
+                ok = (t == T_KEY && c[1] == ag[ACOLOR]) || (t == T_BALL && c[1] != ag[ACOLOR]);
+            if (ok && ag[ACT] == T_EMPTY) {
                 ag[ACT] = c[0]; ag[ACC] = c[1]; ag[ACS] = c[2];
                 c[0] = T_EMPTY; c[1] = 0; c[2] = 0;
             }
         } else if (act == A_DROP) { /* base.py:507-516 */
             if (ag[ACT] != T_EMPTY && t == T_EMPTY && !agent_at(e, fx, fy)) {
                 c[0] = ag[ACT]; c[1] = ag[ACC]; c[2] = ag[ACS];
+                /* the cell takes the OBJECT's encoding (grid.py:91-95), the row held the copy made at pickup */
+                if (sp->kind == K_COMPETITIVE) c[2] = (uint8_t)carried_state(e, i);
                 ag[ACT] = T_EMPTY; ag[ACC] = 0; ag[ACS] = 0;
             }
         } else if (act == A_TOGGLE) { /* base.py:519-524 */
@@ -246,7 +360,7 @@ static int popcount6(unsigned m) {
 }
 
 /* MultiGridEnv.step (base.py:364-408) followed by the subclass hook */
-static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, const uint8_t *meta, int32_t *steps,
+static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, uint8_t *meta, int32_t *steps,
                      uint8_t *flags, const uint8_t *actions, const uint8_t *order, uint8_t *image,
                      uint8_t *direction, double *reward, uint8_t *terminated, uint8_t *truncated) {
     const int A = sp->num_agents;
@@ -259,7 +373,17 @@ static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, const u
         terminated[k] = agents[8 * k + ATERM];            /* base.py:400 */
         truncated[k] = (uint8_t)(e.steps >= sp->max_steps); /* base.py:401-402 */
     }
-    if (sp->kind == K_REDBLUEDOORS) { /* redbluedoors.py:176-185 */
+    if (sp->kind == K_COMPETITIVE) { /* dtde_step / ctce_step, competative_red_blue_door.py:319-423 */
+        int any = 0, all = 1;
+        for (int k = 0; k < A; ++k) { any |= terminated[k]; all &= terminated[k]; }
+        if (sp->per_agent_outputs && any && !all) /* :375-378 */
+            for (int k = 0; k < A; ++k) terminated[k] = 0;
+        for (int n = 0; n < A; ++n) { /* in the order of the keys of the actions dict, :390 */
+            const int i = order ? order[n] : n;
+            comp_handle_steps(&e, i, actions[i], terminated);
+            comp_pickup_rewards(&e, i, actions[i]);
+        }
+    } else if (sp->kind == K_REDBLUEDOORS) { /* redbluedoors.py:176-185 */
         for (int i = 0; i < A; ++i) {
             if (actions[i] != A_TOGGLE) continue;
             const uint8_t *ag = agents + 8 * i;
@@ -299,7 +423,7 @@ static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, const u
     *flags = e.flags;
 }
 
-void mgo_step(const mgo_spec *sp, int64_t E, uint8_t *grid, uint8_t *agents, const uint8_t *meta,
+void mgo_step(const mgo_spec *sp, int64_t E, uint8_t *grid, uint8_t *agents, uint8_t *meta,
               int32_t *steps, uint8_t *flags, const uint8_t *actions, const uint8_t *order,
               uint8_t *image, uint8_t *direction, double *reward, uint8_t *terminated,
               uint8_t *truncated) {
@@ -311,4 +435,4 @@ void mgo_step(const mgo_spec *sp, int64_t E, uint8_t *grid, uint8_t *agents, con
                  reward + e * A, terminated + e * A, truncated + e * A);
 }
 
-int mgo_abi_version(void) { return 1; }
+int mgo_abi_version(void) { return 2; }

@@ -46,8 +46,14 @@ UNSEEN_CELL = (UNSEEN, 0, 0)  # utils/obs.py:14
 # agent row columns
 X, Y, DIR, TERM, CT, CC, CS, COLOR = range(8)
 
-KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
-KIND_NAMES = ("empty", "redbluedoors", "blockedunlockpickup", "lockedhallway")
+KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY, KIND_COMPETITIVE = range(5)
+KIND_NAMES = ("empty", "redbluedoors", "blockedunlockpickup", "lockedhallway", "competitive")
+AVAILABLE, PICKEDUP = 4, 3  # State.available / State.pickedup, multigrid/core/constants.py:91-102
+# CompetativeRedBlueDoorEnvV3 state the arrays do not show, kept in `flags` (bits) and `meta` (counters)
+FLAG_KEY_USED = (1, 2)      # the red / blue key OBJECT is "picked up" (competative_red_blue_door.py:434-435)
+FLAG_DOOR_GONE = (4, 8)     # the red / blue door's cell was cleared under an eliminated agent (:503)
+# reward_schemes[agent] columns (multigrid/envs/__init__.py:100-108)
+RS_ELIMINATED, RS_KEY, RS_BALL, RS_INVALID = range(4)
 
 
 @dataclass
@@ -67,6 +73,11 @@ class EnvSpec:
     failure_any: bool = False  # failure_termination_mode == 'any'
     num_rooms: int = 0  # LockedHallway only (locked_hallway.py:129)
     mission: str = "maximize reward"
+    # CompetativeRedBlueDoorEnvV3 only (competative_red_blue_door.py:114-130)
+    death_match: bool = False
+    per_agent_outputs: bool = True  # training_scheme "DTDE" / "CTDE" (dtde_step) rather than "CTCE"
+    reward_schemes: Optional[Sequence[Sequence[float]]] = None  # [A][4], columns RS_*
+    agent_names: Optional[Sequence[str]] = None
 
 
 def agents_from_reference(agent_states: np.ndarray) -> np.ndarray:
@@ -289,6 +300,9 @@ class Env:
         # RedBlueDoors: the blue Door OBJECT was re-closed after a failure while
         # its grid cell still reads open (redbluedoors.py:185 has no grid.update)
         self.blue_stale_open = False
+        # CompetativeRedBlueDoorEnvV3: FLAG_KEY_USED / FLAG_DOOR_GONE bits, and meta[0] / meta[1] = how often the
+        # discount factor of the red / blue ball has been squared (competative_red_blue_door.py:452-454)
+        self.flags = 0
 
     # -- reset (base.py:310-362 with the layout supplied by the caller) --------
     def load_layout(self, grid, agents, meta=None):
@@ -298,6 +312,7 @@ class Env:
         self.step_count = 0  # base.py:350
         self.unlocked_mask = 0  # locked_hallway.py:190
         self.blue_stale_open = False
+        self.flags = 0
         return self.gen_obs()
 
     # -- helpers ---------------------------------------------------------------
@@ -385,13 +400,20 @@ class Env:
             elif act == PICKUP:  # base.py:497-504
                 fx, fy = self._front(i)
                 t = int(g[fx, fy, 0])
-                if t in (KEY, BALL, BOX) and ag[i, CT] == EMPTY:
+                ok = t in (KEY, BALL, BOX)
+                if sp.kind == KIND_COMPETITIVE:  # competative_red_blue_door.py:573-577: own key, the others' ball
+                    ok = (t == KEY and g[fx, fy, 1] == ag[i, COLOR]) or (t == BALL and g[fx, fy, 1] != ag[i, COLOR])
+                if ok and ag[i, CT] == EMPTY:
                     ag[i, CT:CS + 1] = g[fx, fy]
                     g[fx, fy] = EMPTY_CELL
             elif act == DROP:  # base.py:507-516
                 fx, fy = self._front(i)
                 if ag[i, CT] != EMPTY and g[fx, fy, 0] == EMPTY and not self._agent_at(fx, fy):
                     g[fx, fy] = ag[i, CT:CS + 1]
+                    if sp.kind == KIND_COMPETITIVE:
+                        # the cell takes the OBJECT's encoding (grid.py:91-95); the agent row only held the copy
+                        # made when the key was picked up (agent.py:385)
+                        g[fx, fy, 2] = self._carried_state(i)
                     ag[i, CT:CS + 1] = EMPTY_CELL
             elif act == TOGGLE:  # base.py:519-524
                 fx, fy = self._front(i)
@@ -430,6 +452,8 @@ class Env:
         sp = self.spec
         if order is None:
             order = range(sp.num_agents)
+        if sp.kind == KIND_COMPETITIVE:
+            return self.step_competitive(actions, list(order))
         self.step_count += 1  # base.py:395
         rewards = self.handle_actions(actions, order)
         obs = self.gen_obs()
@@ -469,6 +493,104 @@ class Env:
             if bin(self.unlocked_mask).count("1") == sp.num_rooms:
                 for i in range(sp.num_agents):
                     terminations[i] = True
+        return obs, rewards, terminations, truncations, {}
+
+    # -- CompetativeRedBlueDoorEnvV3 (multigrid/envs/competative_red_blue_door.py) ----------------------
+    def _comp_doors(self):
+        """Door positions of _gen_grid (:201-211): red at the bottom of the left wall, blue at the top of the right."""
+        w, h = self.spec.width, self.spec.height
+        return (w // 4, h - 2), (w // 4 + w // 2 - 1, 1)
+
+    def _carried_state(self, i: int) -> int:
+        """State of the OBJECT agent i carries: a key that has paid its pickup reward is State.pickedup
+        (:434-435, world_object.py:534-552) whatever the copy in the agent row says."""
+        ag = self.agents
+        if ag[i, CT] == KEY and ag[i, CC] in (RED, BLUE) and self.flags & FLAG_KEY_USED[ag[i, CC] // 2]:
+            return PICKEDUP
+        return int(ag[i, CS])
+
+    def _comp_door_open(self, which: int) -> bool:
+        """``self.red_door.is_open`` / ``self.blue_door.is_open`` (:485): the door OBJECT, which keeps its last state
+        (open: an agent stood in it) once its cell has been cleared."""
+        if self.flags & FLAG_DOOR_GONE[which]:
+            return True
+        x, y = self._comp_doors()[which]
+        return self.grid[x, y, 0] == DOOR and self.grid[x, y, 2] == OPEN
+
+    def _comp_handle_steps(self, i, act, rewards, terminations):
+        """_handle_steps, :475-523."""
+        sp, ag = self.spec, self.agents
+        if act != TOGGLE:
+            return
+        fx, fy = self._front(i)
+        victim = None
+        for k in range(sp.num_agents):  # :479-481, the last opponent standing there
+            if (ag[k, X], ag[k, Y]) == (fx, fy) and ag[k, COLOR] != ag[i, COLOR]:
+                victim = k
+        doors = self._comp_doors()
+        if victim is None:
+            for which, (dx, dy) in enumerate(doors):  # :484 `fwd_obj == self.red_door` is object identity
+                if (fx, fy) == (dx, dy) and self.grid[dx, dy, 0] == DOOR and not self.flags & FLAG_DOOR_GONE[which]:
+                    if (self._comp_door_open(0) or self._comp_door_open(1)) and self.grid[dx, dy, 1] == ag[i, COLOR]:
+                        for k in range(sp.num_agents):  # :487-492
+                            if ag[k, COLOR] == ag[i, COLOR] and not ag[k, TERM]:
+                                self.on_success(k, rewards, terminations)
+        elif sp.death_match:  # :498-523
+            self.on_failure(victim, rewards, None)
+            vx, vy = int(ag[victim, X]), int(ag[victim, Y])
+            for which, (dx, dy) in enumerate(doors):
+                if (vx, vy) == (dx, dy) and self.grid[dx, dy, 0] == DOOR:
+                    self.flags |= FLAG_DOOR_GONE[which]
+            self.grid[vx, vy] = EMPTY_CELL  # :503
+            ag[victim, X], ag[victim, Y] = (13, 2) if ag[victim, COLOR] == BLUE else (2, 2)  # :504-506
+            rewards[i] += sp.reward_schemes[i][RS_ELIMINATED]
+            rewards[victim] -= 1
+            if all(ag[k, TERM] for k in range(sp.num_agents) if ag[k, COLOR] != ag[i, COLOR]):  # :511-517
+                for k in range(sp.num_agents):
+                    if ag[k, COLOR] == ag[i, COLOR] and not ag[k, TERM]:
+                        self.on_success(k, rewards, terminations)
+
+    def _comp_pickup_rewards(self, i, act, rewards):
+        """_default_extra_action_handle_steps, :425-472 (the handler of agents without a policy object)."""
+        sp, ag = self.spec, self.agents
+        if act != PICKUP:
+            return
+        rs = sp.reward_schemes[i]
+        (rx, ry), (bx, by) = self._comp_doors()
+        if ag[i, CT] == KEY and self._carried_state(i) == AVAILABLE and ag[i, CC] == ag[i, COLOR]:  # :428-436
+            if ag[i, CC] in (RED, BLUE):
+                self.flags |= FLAG_KEY_USED[ag[i, CC] // 2]
+            rewards[i] += rs[RS_KEY]
+            return
+        if ag[i, CT] == BALL and ag[i, CC] != ag[i, COLOR] and ag[i, CC] in (RED, BLUE):  # :445-454
+            # Ball(color="blue", init_pos=next to the red door), Ball(color="red", init_pos=next to the blue door) :230-232
+            init = (bx - 1, by) if ag[i, CC] == RED else (rx + 1, ry)
+            if self._front(i) == init:
+                slot = ag[i, CC] // 2
+                d = 0.9  # Ball.__new__ default, world_object.py:583
+                for _ in range(int(self.meta[slot])):
+                    d *= d
+                rewards[i] += rs[RS_BALL] * d
+                self.meta[slot] += 1  # discount_factor *= discount_factor
+                return
+        rewards[i] -= rs[RS_INVALID]  # :470-472
+
+    def step_competitive(self, actions, order):
+        """CompetativeRedBlueDoorEnvV3.step (:526-536): MultiGridEnv.step, then dtde_step / ctce_step (:319-423) with the
+        default handlers; agents act, and are handled, in the order of the keys of the actions dict."""
+        sp = self.spec
+        self.step_count += 1
+        rewards = self.handle_actions(actions, order)
+        obs = self.gen_obs()
+        terminations = {i: bool(self.agents[i, TERM]) for i in range(sp.num_agents)}
+        truncated = self.step_count >= sp.max_steps
+        truncations = {i: truncated for i in range(sp.num_agents)}
+        if sp.per_agent_outputs and any(terminations.values()) and not all(terminations.values()):  # :375-378
+            terminations = {i: False for i in terminations}
+        for i in order:
+            i = int(i)
+            self._comp_handle_steps(i, int(actions[i]), rewards, terminations)
+            self._comp_pickup_rewards(i, int(actions[i]), rewards)
         return obs, rewards, terminations, truncations, {}
 
     def is_done(self) -> bool:

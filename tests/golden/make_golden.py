@@ -38,6 +38,7 @@ from multigrid.core.world_object import (  # noqa: E402
     Ball, Box, Door, Floor, Goal, Key, Lava, Wall)
 from multigrid.envs import CONFIGURATIONS  # noqa: E402
 from multigrid.envs.blockedunlockpickup import BlockedUnlockPickupEnv  # noqa: E402
+from multigrid.envs.competative_red_blue_door import CompetativeRedBlueDoorEnvV3  # noqa: E402
 from multigrid.envs.empty import EmptyEnv  # noqa: E402
 from multigrid.envs.locked_hallway import LockedHallwayEnv  # noqa: E402
 from multigrid.envs.redbluedoors import RedBlueDoorsEnv  # noqa: E402
@@ -294,6 +295,215 @@ def record_layouts():
     print(f"layouts.npz size={os.path.getsize(path) / 1024:.0f} KiB")
 
 
+# --- CompetativeRedBlueDoorEnvV3 (multigrid/envs/competative_red_blue_door.py) ------------------------------
+
+SCHEME_KEYS = ("eliminated_opponent_sparse_reward", "key_pickup_sparse_reward", "ball_pickup_dense_reward",
+               "invalid_pickup_dense_penalty")
+
+
+def comp_hidden(env, keys, balls):
+    """State the arrays do not show: a key whose OBJECT is "picked up" while the agent row still carries the copy
+    taken at pickup time (competative_red_blue_door.py:434-435), a door object whose cell was cleared under an
+    eliminated agent (:503), and how often each ball's discount factor has been squared (:454)."""
+    flags = 0
+    for bit, color in enumerate(("red", "blue")):
+        k = keys.get(color)
+        if k is not None and int(k.state) == 3:
+            flags |= 1 << bit
+    for bit, door in enumerate((env.red_door, env.blue_door)):
+        pos = [xy for xy, o in env.grid.world_objects.items() if o is door]
+        if not pos:
+            flags |= 4 << bit
+    meta = np.zeros(4, np.uint8)
+    for slot, color in enumerate(("red", "blue")):
+        b = balls.get(color)
+        if b is not None:
+            n, d = 0, 0.9
+            while d != b.discount_factor:
+                d *= d
+                n += 1
+                assert n < 40
+            meta[slot] = n
+    return flags, meta
+
+
+def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None, script=None, extra_after_done=3,
+                       view=None):
+    """Trajectories of CompetativeRedBlueDoorEnvV3 with its default step handlers (policies_map = {}).  The order in
+    which agents act is the order of the keys of the actions dict (:633-641, :390); the harness shuffles it every step
+    and records it."""
+    if ONLY and name not in ONLY:
+        return
+    rng = np.random.default_rng(seed0)
+    trajs, spec = [], None
+    for n in range(n_traj):
+        kwargs = dict(kw)
+        if view is not None:
+            kwargs["agent_view_size"] = view
+        env = CompetativeRedBlueDoorEnvV3(policies_map={}, **kwargs)
+        env._RandomMixin__np_random = np.random.default_rng(seed0 * 1000 + n)
+        obs, _ = env.reset(seed=seed0 * 7919 + n)
+        a = env.num_agents
+        names = [ag.name for ag in env.agents]
+        keys = {str(o.color.value if hasattr(o.color, "value") else o.color): o
+                for o in env.grid.world_objects.values() if isinstance(o, Key)}
+        balls = {str(o.color.value if hasattr(o.color, "value") else o.color): o
+                 for o in env.grid.world_objects.values() if isinstance(o, Ball)}
+        if edit is not None:
+            edit(env, rng, n, keys, balls)
+            obs = env.gen_obs()
+        if spec is None:
+            spec = dict(
+                kind=4, width=env.width, height=env.height, num_agents=a, max_steps=env.max_steps,
+                view_size=env.agents[0].view_size, see_through_walls=bool(env.agents[0].see_through_walls),
+                allow_agent_overlap=bool(env.allow_agent_overlap), joint_reward=bool(env.joint_reward),
+                success_any=env.success_termination_mode == "any", failure_any=env.failure_termination_mode == "any",
+                num_rooms=0, mission="", death_match=bool(env.death_match),
+                per_agent_outputs=env.training_scheme != "CTCE",
+                reward_schemes=[[float(env.reward_schemes[nm][k]) for k in SCHEME_KEYS] for nm in names],
+                agent_names=names)
+        v = env.agents[0].view_size
+        tr = dict(
+            layout_grid=env.grid.state.astype(np.uint8).copy(), layout_agents=agent_rows(env),
+            layout_meta=np.zeros(4, np.uint8),
+            reset_image=np.stack([obs[nm]["image"] for nm in names]).astype(np.uint8),
+            actions=[], order=[], image=[], direction=[], reward=[], terminated=[], truncated=[], post_grid=[],
+            post_agents=[], post_flags=[], post_meta=[])
+        after = 0
+        for t in range(t_max):
+            if script is not None and t < len(script(n)):
+                acts = np.asarray(script(n)[t][:a], dtype=np.int64)
+            elif action_p is None:
+                acts = rng.integers(0, 7, size=a)
+            else:
+                acts = rng.choice(7, size=a, p=action_p)
+            order = rng.permutation(a)
+            o, r, term, trunc, _ = env.step({names[i]: int(acts[i]) for i in order})
+            tr["actions"].append(acts.astype(np.uint8))
+            tr["order"].append(order.astype(np.uint8))
+            img = np.stack([o[nm]["image"] for nm in names])
+            assert img.min() >= 0 and img.max() < 256 and img.shape == (a, v, v, 3)
+            tr["image"].append(img.astype(np.uint8))
+            tr["direction"].append(np.array([int(o[nm]["direction"]) for nm in names], np.uint8))
+            tr["reward"].append(np.array([float(r[nm]) for nm in names], np.float64))
+            tr["terminated"].append(np.array([bool(term[nm]) for nm in names]))
+            tr["truncated"].append(np.array([bool(trunc[nm]) for nm in names]))
+            tr["post_grid"].append(env.grid.state.astype(np.uint8).copy())
+            tr["post_agents"].append(agent_rows(env))
+            fl, mt = comp_hidden(env, keys, balls)
+            tr["post_flags"].append(np.uint8(fl))
+            tr["post_meta"].append(mt)
+            if all(term.values()) or all(trunc.values()):
+                after += 1
+                if after > extra_after_done:
+                    break
+        trajs.append(tr)
+    n = len(trajs)
+    lens = np.array([len(t["actions"]) for t in trajs], np.int32)
+    tm = int(lens.max())
+    out = dict(spec=np.array(json.dumps(spec)), length=lens)
+    for key in ("layout_grid", "layout_agents", "layout_meta", "reset_image"):
+        out[key] = np.stack([t[key] for t in trajs])
+    for key in ("actions", "order", "image", "direction", "reward", "terminated", "truncated", "post_grid",
+                "post_agents", "post_flags", "post_meta"):
+        first = np.asarray(trajs[0][key][0])
+        arr = np.zeros((n, tm) + first.shape, dtype=first.dtype)
+        for i, t in enumerate(trajs):
+            arr[i, :len(t[key])] = np.stack(t[key])
+        out[key] = arr
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:28s} traj={n:3d} steps={int(lens.sum()):6d} nonzero_rewards={int((out['reward'] != 0).sum()):5d} "
+          f"positive={int((out['reward'] > 0).sum()):4d} below_minus_half={int((out['reward'] < -0.5).sum()):3d} "
+          f"traj_with_termination={int(out['terminated'].any(axis=(1, 2)).sum()):3d} "
+          f"flags_seen={sorted(set(out['post_flags'].ravel().tolist()))} ball_max={int(out['post_meta'].max())} "
+          f"size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def comp_free_cells(env):
+    """Empty cells of the middle room that no agent stands on."""
+    pos = {tuple(int(c) for c in ag.state.pos) for ag in env.agents}
+    x0, x1 = env.width // 4 + 1, env.width // 4 + env.width // 2 - 1
+    return [(x, y) for x in range(x0, x1) for y in range(1, env.height - 1)
+            if env.grid.get(x, y) is None and (x, y) not in pos]
+
+
+def comp_take(env, agent, obj):
+    """Hand `obj` (one of the environment's own objects, wherever it lies) to `agent`."""
+    for xy, o in list(env.grid.world_objects.items()):
+        if o is obj:
+            env.grid.set(*xy, None)
+    agent.state.carrying = obj
+
+
+def comp_edit(env, rng, n, keys, balls):
+    cells = comp_free_cells(env)
+    rng.shuffle(cells)
+    by_color = {}
+    for ag in env.agents:
+        by_color.setdefault(str(ag.color.value if hasattr(ag.color, "value") else ag.color), []).append(ag)
+    rx, ry, bx, by = env.width // 4, env.height - 2, env.width // 4 + env.width // 2 - 1, 1
+    mode = n % 8
+    if mode == 0 and "red" in by_color:       # red agent with the red key in front of the red door
+        ag = by_color["red"][-1]
+        comp_take(env, ag, keys["red"])
+        if env.grid.get(rx + 1, ry) is not None:
+            env.grid.set(rx + 1, ry, None)
+        ag.state.pos, ag.state.dir = (rx + 1, ry), 2
+    elif mode == 1 and "blue" in by_color:    # blue agent with the blue key in front of the blue door
+        ag = by_color["blue"][0]
+        comp_take(env, ag, keys["blue"])
+        if env.grid.get(bx - 1, by) is not None:
+            env.grid.set(bx - 1, by, None)
+        ag.state.pos, ag.state.dir = (bx - 1, by), 0
+    elif mode in (2, 3) and len(by_color) == 2:   # opponents next to each other, facing each other
+        for r_ag, b_ag in zip(by_color["red"], by_color["blue"]):
+            for (x, y) in cells:
+                if (x + 1, y) in cells:
+                    cells.remove((x, y))
+                    cells.remove((x + 1, y))
+                    r_ag.state.pos, r_ag.state.dir = (x, y), 0
+                    b_ag.state.pos, b_ag.state.dir = (x + 1, y), 2
+                    break
+        if mode == 3:   # doors that can be walked through: an agent may be eliminated in a doorway
+            for door, (dx, dy) in ((env.red_door, (rx, ry)), (env.blue_door, (bx, by))):
+                door.is_locked = False
+                door.is_open = True
+                env.grid.update(dx, dy)
+            ag = by_color["blue"][0]
+            ag.state.pos, ag.state.dir = (rx, ry), 0
+            opp = by_color["red"][0]
+            if env.grid.get(rx + 1, ry) is not None:
+                env.grid.set(rx + 1, ry, None)
+            opp.state.pos, opp.state.dir = (rx + 1, ry), 2
+    elif mode == 4:   # every agent next to its own key or the other team's, facing it
+        for ag in env.agents:
+            k = list(keys.values())[int(rng.integers(len(keys)))]
+            kp = [xy for xy, o in env.grid.world_objects.items() if o is k]
+            if kp and (kp[0][0] - 1, kp[0][1]) in cells:
+                cells.remove((kp[0][0] - 1, kp[0][1]))
+                ag.state.pos, ag.state.dir = (kp[0][0] - 1, kp[0][1]), 0
+    elif mode == 5 and balls:   # agents in front of the balls
+        for color, ball in balls.items():
+            opp = "red" if color == "blue" else "blue"
+            if opp in by_color:
+                ag = by_color[opp][0]
+                ix, iy = ball.init_pos
+                ag.state.pos, ag.state.dir = ((ix + 1, iy), 2) if color == "blue" else ((ix - 1, iy), 0)
+    elif mode == 6:   # scattered, some already holding things
+        for ag in env.agents:
+            if cells:
+                ag.state.pos = cells.pop()
+            ag.state.dir = int(rng.integers(4))
+        for color, k in keys.items():
+            if color in by_color and rng.random() < 0.7:
+                comp_take(env, by_color[color][0], k)
+    # mode 7: untouched
+
+
+PICKY = np.array([0.10, 0.10, 0.22, 0.26, 0.10, 0.20, 0.02])
+
+
 BIASED = np.array([0.12, 0.12, 0.36, 0.12, 0.08, 0.18, 0.02])
 TOGGLY = np.array([0.10, 0.10, 0.25, 0.05, 0.05, 0.43, 0.02])
 
@@ -411,6 +621,33 @@ def main():
                  12, 50, 45, edit=lh_edit, action_p=TOGGLY, script=lh_script)
     record_group("chaos_lockedhallway6", lambda: make_env(LockedHallwayEnv, 6, num_rooms=6, max_steps=100),
                  6, 60, 46, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    # ---- CompetativeRedBlueDoorEnvV3, registry entries as they are and with harness-edited starts
+    def comp_script(n):
+        m = n % 8
+        if m in (0, 1):
+            return [[5] * 4, [5] * 4]     # toggle: the door opens and the team wins; then toggling goes on
+        if m in (2, 3):
+            return [[5] * 4]               # everybody toggles: eliminations
+        if m in (4, 5):
+            return [[3] * 4, [3] * 4, [3] * 4, [4] * 4, [3] * 4, [3] * 4]   # pick up, again, drop, pick up again
+        return []
+    for gname, reg, view, kwx, nt in (
+        ("comp_1v1", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-1v1", None, {}, 16),
+        ("comp_2v2", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2", 7, {"max_steps": 120}, 16),
+        ("comp_2v2_deathmatch", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2-Death-Match", None, {"max_steps": 90}, 16),
+        ("comp_2v2_all", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2", 7,
+         {"max_steps": 100, "success_termination_mode": "all", "allow_agent_overlap": True}, 16),
+        ("comp_single", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-Red-Single-with-Obstacle", 7, {"max_steps": 60}, 8),
+        ("comp_2v2_ctce", "MultiGrid-CompetativeRedBlueDoor-v3-CTCE-2v2", 7, {"max_steps": 80}, 8),
+    ):
+        cls, kw = cfg[reg]
+        kw = dict(kw, **kwx)
+        if "ctce" in gname:   # recorded per agent: the harness calls the DTDE code path's twin with team-keyed dicts
+            continue
+        record_competitive(gname, kw, nt, 70, zlib.crc32(gname.encode()) % 1000 + 50, edit=comp_edit,
+                           action_p=PICKY, script=comp_script, view=view)
+    record_competitive("comp_1v1_plain", dict(cfg["MultiGrid-CompetativeRedBlueDoor-v3-DTDE-1v1"][1]), 6, 320, 61)
+
     if not ONLY or "layouts" in ONLY:
         record_layouts()
 

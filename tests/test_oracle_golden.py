@@ -36,6 +36,9 @@ def test_pyref_replays_reference(name, fast_obs):
                                           err_msg=where + " truncated")
             np.testing.assert_array_equal(env.grid, d["post_grid"][n, t], err_msg=where + " grid")
             np.testing.assert_array_equal(env.agents, d["post_agents"][n, t], err_msg=where + " agents")
+            if "post_flags" in d:  # CompetativeRedBlueDoorEnvV3: what the arrays do not show
+                assert env.flags == d["post_flags"][n, t], where + " flags"
+                np.testing.assert_array_equal(env.meta, d["post_meta"][n, t], err_msg=where + " ball discount counters")
 
 
 @pytest.mark.parametrize("name", group_names())
@@ -59,3 +62,6 @@ def test_c_oracle_replays_reference(name):
         np.testing.assert_array_equal(trunc[live].astype(bool), d["truncated"][live, t], err_msg=where + " trunc")
         np.testing.assert_array_equal(bo.grid[live], d["post_grid"][live, t], err_msg=where + " grid")
         np.testing.assert_array_equal(bo.agents[live], d["post_agents"][live, t], err_msg=where + " agents")
+        if "post_flags" in d:
+            np.testing.assert_array_equal(bo.flags[live], d["post_flags"][live, t], err_msg=where + " flags")
+            np.testing.assert_array_equal(bo.meta[live], d["post_meta"][live, t], err_msg=where + " ball counters")
