@@ -11,4 +11,4 @@ RED, GREEN, BLUE, PURPLE, YELLOW, GREY = range(6)
 OPEN, CLOSED, LOCKED, PICKEDUP, AVAILABLE, ALIVE, DEAD = range(7)
 LEFT, RIGHT, FORWARD, PICKUP, DROP, TOGGLE, DONE = range(7)
 
-KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
+KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY, KIND_COMPETITIVE = range(5)

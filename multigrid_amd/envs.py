@@ -9,7 +9,7 @@ from functools import partial
 from typing import Callable, Dict, Tuple
 
 from . import layouts
-from .constants import (COLOR_NAMES, KIND_BLOCKEDUNLOCKPICKUP, KIND_EMPTY, KIND_LOCKEDHALLWAY,
+from .constants import (COLOR_NAMES, KIND_BLOCKEDUNLOCKPICKUP, KIND_COMPETITIVE, KIND_EMPTY, KIND_LOCKEDHALLWAY,
                         KIND_REDBLUEDOORS)
 
 # name -> (environment family, registry kwargs)
@@ -27,6 +27,38 @@ CONFIGURATIONS: Dict[str, Tuple[str, dict]] = {
     "MultiGrid-RedBlueDoors-6x6-v0": ("redbluedoors", {"size": 6}),
     "MultiGrid-RedBlueDoors-8x8-v0": ("redbluedoors", {"size": 8}),
 }
+
+
+# CompetativeRedBlueDoorEnvV3 entries, multigrid/envs/__init__.py:90-614.  Every entry gives every agent the same
+# reward scheme (:100-108); a caller may pass its own ``reward_schemes={"red_0": {...}, ...}``.
+DEFAULT_REWARD_SCHEME = {"eliminated_opponent_sparse_reward": 0.5, "key_pickup_sparse_reward": 0.5,
+                         "ball_pickup_dense_reward": 0.5, "invalid_pickup_dense_penalty": 0.001}
+REWARD_SCHEME_KEYS = ("eliminated_opponent_sparse_reward", "key_pickup_sparse_reward", "ball_pickup_dense_reward",
+                      "invalid_pickup_dense_penalty")
+
+
+def _competitive(teams, scheme, obstacle, death_match=False, randomization=False, max_steps=None):
+    kw = {"size": 8, "allow_agent_overlap": False, "has_obsticle": obstacle, "death_match": death_match,
+          "teams": teams, "training_scheme": scheme, "randomization": randomization}
+    if max_steps:
+        kw["max_steps"] = max_steps
+    return ("competitive", kw)
+
+
+_V3 = "MultiGrid-CompetativeRedBlueDoor-v3-"
+_TWO = {"blue": 2, "red": 2}
+CONFIGURATIONS.update({
+    _V3 + "DTDE-Red-Single": _competitive({"red": 1}, "DTDE", False),
+    _V3 + "DTDE-Red-Single-with-Obstacle": _competitive({"red": 1}, "DTDE", True),
+    **{_V3 + f"{s}-Red": _competitive({"red": 2}, s, True, randomization=True) for s in ("CTCE", "DTDE", "CTDE")},
+    **{_V3 + f"{s}-Red-Eval": _competitive({"red": 2}, s, True, randomization=True, max_steps=300)
+       for s in ("CTCE", "DTDE", "CTDE")},
+    **{_V3 + f"{s}-1v1": _competitive({"blue": 1, "red": 1}, s, False, True, True, 300) for s in ("DTDE", "CTCE")},
+    _V3 + "CTCE-2v2": _competitive(_TWO, "CTCE", True, True),
+    _V3 + "DTDE-2v2": _competitive(_TWO, "DTDE", True, True),
+    _V3 + "CTDE-2v2": _competitive(_TWO, "CTDE", True, False),
+    **{_V3 + f"{s}-2v2-Death-Match": _competitive(_TWO, s, False, True) for s in ("CTDE", "CTCE", "DTDE")},
+})
 
 
 def default_teams(num_agents: int) -> Dict[str, int]:
@@ -58,6 +90,10 @@ def make_spec(name: str, num_agents: int | None = None, teams: Dict[str, int] | 
     """
     family, reg = CONFIGURATIONS[name]
     kw = dict(reg, **kwargs)
+    if family == "competitive":  # the registry entries of this family name their teams themselves
+        teams = teams if teams is not None else kw["teams"]
+        kw.pop("teams")
+        kw.pop("agents", None)
     if teams is None:
         teams = default_teams(num_agents if num_agents is not None else 1)
     colors = agent_colors(teams)
@@ -103,6 +139,23 @@ def make_spec(name: str, num_agents: int | None = None, teams: Dict[str, int] | 
         gen = partial(layouts.gen_lockedhallway, num_rooms=rooms, agent_colors=colors, room_size=rs,
                       max_hallway_keys=kw.pop("max_hallway_keys", 1),
                       max_keys_per_room=kw.pop("max_keys_per_room", 2))
+    elif family == "competitive":  # multigrid/envs/competative_red_blue_door.py:114-183
+        size = kw.pop("size", 8)
+        names = [f"{team}_{i}" for team, n in teams.items() for i in range(n)]  # base.py:186-190
+        schemes = kw.pop("reward_schemes", None) or {n: DEFAULT_REWARD_SCHEME for n in names}
+        scheme = kw.pop("training_scheme", "CTCE")
+        spec.update(kind=KIND_COMPETITIVE, width=2 * size, height=size,
+                    max_steps=kw.pop("max_steps", None) or 20 * size ** 2,
+                    joint_reward=kw.pop("joint_reward", False),
+                    failure_any=kw.pop("failure_termination_mode", "all") == "any",
+                    death_match=bool(kw.pop("death_match", False)),
+                    # dtde_step (DTDE / CTDE) returns one entry per agent, ctce_step one per team (:319-423)
+                    per_agent_outputs=scheme != "CTCE", training_scheme=scheme,
+                    reward_schemes=[[float(schemes[n][k]) for k in REWARD_SCHEME_KEYS] for n in names],
+                    agent_names=names, mission="Go pick up the key or the ball for opening the door")
+        gen = partial(layouts.gen_competitive, size=size, agent_colors=colors,
+                      team_colors=[COLOR_NAMES.index(t) for t in teams],
+                      has_obstacle=bool(kw.pop("has_obsticle", False)), randomization=bool(kw.pop("randomization", False)))
     else:
         raise KeyError(family)
     if kw:

@@ -20,7 +20,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .constants import (BALL, BLUE, BOX, COLOR_NAMES, DOOR, EMPTY, GOAL, GREEN, KEY, LOCKED, RED,
+from .constants import (AVAILABLE, BALL, BLUE, BOX, COLOR_NAMES, DOOR, EMPTY, GOAL, GREEN, KEY, LOCKED, RED,
                         TYPE_NAMES, WALL, GREY)
 
 Layout = Tuple[np.ndarray, np.ndarray, np.ndarray, str]
@@ -241,6 +241,45 @@ def gen_lockedhallway(num_rooms: int, agent_colors: Sequence[int], mixin_rng, en
     for k in range(len(agent_colors)):
         b.place_agent(k, hallway_top, hallway_size)
     return b.finish(mission="open all the doors")
+
+
+def gen_competitive(size: int, agent_colors: Sequence[int], mixin_rng, env_rng=None, team_colors: Sequence[int] = (RED,),
+                    has_obstacle: bool = False, randomization: bool = False) -> Layout:
+    """CompetativeRedBlueDoorEnvV3._gen_grid, multigrid/envs/competative_red_blue_door.py:185-242.  ``team_colors``:
+    the colours of the teams in the order of the ``teams`` dict (one key per team is placed in that order)."""
+    w, h = 2 * size, size
+    b = _Builder(w, h, agent_colors, mixin_rng, env_rng)
+    room_top, room_size = (w // 4, 0), (w // 2, h)
+    b.wall_rect(0, 0, w, h)
+    b.wall_rect(*room_top, *room_size)
+    rx, ry = room_top[0], h - 2                       # red door at the bottom of the left wall (:201-205)
+    b.grid[rx, ry] = (DOOR, RED, LOCKED)
+    bx, by = room_top[0] + room_size[0] - 1, 1        # blue door at the top of the right wall (:207-211)
+    b.grid[bx, by] = (DOOR, BLUE, LOCKED)
+    # Agents in the order sorted(key=(color == 'blue', color)) (:215): each is first placed at random (which
+    # draws from the generator) and then moved to its fixed start next to the OTHER team's door.
+    names = [COLOR_NAMES[c] for c in agent_colors]
+    for idx, k in enumerate(sorted(range(len(names)), key=lambda k: (names[k] == "blue", names[k]))):
+        if names[k] == "red":
+            b.place_agent(k, top=(rx + 2, ry), size=(4, 4))
+            b.pos[k], b.dir[k] = (bx - (idx + 2), by), 2
+        else:
+            b.place_agent(k, top=(bx - 1, by), size=(4, 4))
+            b.pos[k], b.dir[k] = (rx + (idx + 1 if idx == 1 else idx), ry), 0
+    if has_obstacle:                                   # a ball of the other colour in front of each door (:228-232)
+        if RED in team_colors:
+            b.grid[rx + 1, ry] = (BALL, BLUE, 0)
+        if BLUE in team_colors:
+            b.grid[bx - 1, by] = (BALL, RED, 0)
+    key_positions = {RED: (7, 4), BLUE: (8, 3)}        # :236
+    for c in team_colors:
+        if randomization:
+            b.place_obj((KEY, c, AVAILABLE), room_top, room_size)
+        else:
+            b.place_obj((KEY, c, AVAILABLE), key_positions[c], (1, 1))
+    # the mission text is drawn from the mission space's own generator (base.py:329-330); the first of its
+    # four texts (:161-166) stands for it here
+    return b.finish(mission="Go pick up the key or the ball for opening the door")
 
 
 def make_pool(gen, n: int, seed0: int = 0, **kw) -> Tuple[np.ndarray, np.ndarray, np.ndarray, List[str]]:

@@ -272,11 +272,15 @@ def record_layouts():
                          ("MultiGrid-LockedHallway-2Rooms-v0", 2),
                          ("MultiGrid-LockedHallway-6Rooms-v0", 3),
                          ("MultiGrid-Empty-16x16-v0", 8), ("MultiGrid-RedBlueDoors-6x6-v0", 3),
-                         ("MultiGrid-Empty-Random-6x6-v0", 3)):
+                         ("MultiGrid-Empty-Random-6x6-v0", 3),
+                         ("MultiGrid-CompetativeRedBlueDoor-v3-DTDE-1v1", 2),
+                         ("MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2", 4),
+                         ("MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2-Death-Match", 4),
+                         ("MultiGrid-CompetativeRedBlueDoor-v3-DTDE-Red-Single-with-Obstacle", 1)):
         cls, kw = CONFIGURATIONS[name]
         grids, ags, metas, missions = [], [], [], []
         for seed in range(24):
-            env = make_env(cls, agents, **kw)
+            env = cls(policies_map={}, **kw) if cls is CompetativeRedBlueDoorEnvV3 else make_env(cls, agents, **kw)
             env._RandomMixin__np_random = np.random.default_rng(seed)
             env.reset(seed=seed + 100)
             grids.append(env.grid.state.astype(np.uint8).copy())
