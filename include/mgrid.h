@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 4
+#define MG_ABI_VERSION 5
 
 /* error codes */
 #define MG_OK 0
@@ -46,6 +46,13 @@ extern "C" {
 #define MG_KIND_REDBLUEDOORS 1        /* multigrid/envs/redbluedoors.py:170-187 */
 #define MG_KIND_BLOCKEDUNLOCKPICKUP 2 /* multigrid/envs/blockedunlockpickup.py:160-169 */
 #define MG_KIND_LOCKEDHALLWAY 3       /* multigrid/envs/locked_hallway.py:193-217 */
+#define MG_KIND_COMPETITIVE 4         /* CompetativeRedBlueDoorEnvV3 with its default step handlers,
+                                         multigrid/envs/competative_red_blue_door.py:372-536: colour-restricted pickup
+                                         (:573-577), team win at the own door (:484-495), death-match eliminations
+                                         (:498-523), pickup rewards and penalty (:425-472); at most 8 agents; agents
+                                         act in `order_dev` order = the order of the caller's actions dict (:633-641),
+                                         index order when order_dev is NULL.  Not reproduced: policy objects
+                                         (`policies_map`), the info dicts and the mission texts. */
 
 /* what happens to an environment whose episode ended in this step */
 #define MG_AUTORESET_NONE 0      /* nothing: the caller resets with mg_reset (reference behaviour) */
@@ -75,6 +82,12 @@ typedef struct MgConfig {
     int32_t autoreset;           /* MG_AUTORESET_* */
     int32_t env_id_offset;       /* global index of environment 0 (sharded runs); it seeds the
                                     layout choice and the on-device agent-order generator */
+    int32_t death_match;         /* MG_KIND_COMPETITIVE: toggling an opponent eliminates it
+                                    (competative_red_blue_door.py:124,498); needs the 16 x 8 grid */
+    int32_t per_agent_outputs;   /* MG_KIND_COMPETITIVE: training_scheme "DTDE" / "CTDE" (dtde_step, :372-423,
+                                    which reports no termination while only some agents are terminated,
+                                    :375-378) rather than "CTCE" (ctce_step, :319-370; sum the rewards and AND
+                                    the flags per team on the caller's side) */
     uint64_t seed;               /* seed of the on-device agent-order generator */
 } MgConfig;
 
@@ -108,6 +121,11 @@ const char *mg_last_error(MgHandle h);
  * of the layout's grid (MG_EINVAL otherwise). */
 int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, const uint8_t *meta,
                       int32_t n);
+
+/* MG_KIND_COMPETITIVE: the agents' reward schemes (`reward_schemes[agent.name]`, multigrid/envs/__init__.py:100-108),
+ * HOST pointer to double [A][4]: eliminated_opponent_sparse_reward, key_pickup_sparse_reward,
+ * ball_pickup_dense_reward, invalid_pickup_dense_penalty.  All zero until set.  Synchronous. */
+int mg_set_reward_schemes(MgHandle h, const double *schemes);
 
 /* Parameters of the `_gen_grid` procedures that MgConfig does not carry. */
 typedef struct MgLayoutSpec {
@@ -181,6 +199,10 @@ int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint
  * steps int32[E] = step_count (base.py:350,395); flags uint8[E]: bits 0-5 LockedHallway doors
  * already rewarded, by door colour (locked_hallway.py:204-205); bit 7: RedBlueDoors blue door
  * object re-closed after a failure while its grid cell still reads open (redbluedoors.py:185).
+ * MG_KIND_COMPETITIVE keeps there what the reference keeps in objects: flags bit 0 / 1 = the red / blue key
+ * object is "picked up" (competative_red_blue_door.py:434-435) although the agent row still shows the copy
+ * taken at pickup time; bit 2 / 3 = the red / blue door's cell was cleared under an eliminated agent (:503);
+ * meta[0] / meta[1] = how often the red / blue ball's discount factor has been squared (:452-454).
  * Any pointer may be NULL.  mg_set_state first checks `grid_dev` and `agents_dev` against the field limits
  * at the top of this file (waiting for the stream) and returns MG_EINVAL, leaving the state untouched, when a
  * value does not fit. */

@@ -16,13 +16,14 @@ SRC_PATH = os.path.join(PKG_DIR, "csrc", "mgrid.hip")
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
 MG_OK = 0
-KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY = range(4)
+KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY, KIND_COMPETITIVE = range(5)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
+           "mg_set_reward_schemes",
            "mg_reset", "mg_step", "mg_step_n", "mg_gen_obs", "mg_gen_obs_of_state", "mg_get_state", "mg_set_state",
            "mg_stats")
 
@@ -31,7 +32,8 @@ class MgConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "kind", "width", "height", "num_agents", "view_size", "max_steps", "see_through_walls",
         "allow_agent_overlap", "joint_reward", "success_any", "failure_any", "num_rooms",
-        "num_envs", "device", "autoreset", "env_id_offset")] + [("seed", ctypes.c_uint64)]
+        "num_envs", "device", "autoreset", "env_id_offset", "death_match", "per_agent_outputs")] + [
+        ("seed", ctypes.c_uint64)]
 
 
 class MgOut(ctypes.Structure):
@@ -80,6 +82,7 @@ def lib() -> ctypes.CDLL:
         L.mg_last_error.argtypes = [vp]
         L.mg_last_error.restype = ctypes.c_char_p
         L.mg_upload_layouts.argtypes = [vp, vp, vp, vp, i32]
+        L.mg_set_reward_schemes.argtypes = [vp, vp]
         L.mg_generate_layouts.argtypes = [vp, ctypes.POINTER(MgLayoutSpec), i32, ctypes.c_uint64]
         L.mg_reset.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]

@@ -79,9 +79,15 @@ class BatchedMultiGrid:
             joint_reward=int(bool(spec["joint_reward"])), success_any=int(bool(spec["success_any"])),
             failure_any=int(bool(spec["failure_any"])), num_rooms=int(spec.get("num_rooms", 0)),
             num_envs=self.E, device=dev.index or 0, autoreset=int(autoreset),
-            env_id_offset=int(env_id_offset), seed=int(seed))
+            env_id_offset=int(env_id_offset), death_match=int(bool(spec.get("death_match", False))),
+            per_agent_outputs=int(bool(spec.get("per_agent_outputs", True))), seed=int(seed))
         self._h = ctypes.c_void_p()
         check(_lib.lib().mg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        if int(spec["kind"]) == _lib.KIND_COMPETITIVE:  # reward_schemes of multigrid/envs/__init__.py:100-108
+            rs = np.ascontiguousarray(spec["reward_schemes"], np.float64)
+            if rs.shape != (self.A, 4):
+                raise ValueError(f"reward_schemes must be [{self.A}][4], got {rs.shape}")
+            check(_lib.lib().mg_set_reward_schemes(self._h, rs.ctypes.data), self._h)
         e, a, v = self.E, self.A, self.V
         self.out = StepOutput(
             image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev) if compact_image or not one_hot else None,

@@ -57,13 +57,21 @@ namespace {
 
 // ---- encodings (multigrid/core/constants.py:32-102, multigrid/core/actions.py:4-15) ----------
 enum : int { T_UNSEEN, T_EMPTY, T_WALL, T_FLOOR, T_DOOR, T_KEY, T_BALL, T_BOX, T_GOAL, T_LAVA, T_AGENT };
-enum : int { S_OPEN, S_CLOSED, S_LOCKED };
+enum : int { S_OPEN, S_CLOSED, S_LOCKED, S_PICKEDUP, S_AVAILABLE };
+enum : int { C_RED = 0, C_BLUE = 2 };  // multigrid/core/constants.py:50-59
 enum : int { ACT_LEFT, ACT_RIGHT, ACT_FORWARD, ACT_PICKUP, ACT_DROP, ACT_TOGGLE, ACT_DONE };
 enum : int { R_X, R_Y, R_DIR, R_TERM, R_CT, R_CC, R_CS, R_COLOR };
 
 constexpr uint32_t FLAG_LH_MASK = 0x3F;  // LockedHallway: doors already rewarded, by colour
 constexpr uint32_t FLAG_OVER = 0x40;     // episode already counted as finished
 constexpr uint32_t FLAG_STALE = 0x80;    // RedBlueDoors: blue door object closed, cell reads open
+// CompetativeRedBlueDoorEnvV3 (multigrid/envs/competative_red_blue_door.py): what the arrays do not show
+constexpr uint32_t FLAG_KEY_USED = 0x01;   // << 0 / 1: the red / blue key OBJECT is "picked up" (:434-435) while the
+                                           // agent row still holds the copy made when it was picked up
+constexpr uint32_t FLAG_DOOR_GONE = 0x04;  // << 0 / 1: the red / blue door's cell was cleared under an eliminated
+                                           // agent (:503); the orphaned door object stays open
+// meta[0] / meta[1] of such an environment: how often the red / blue ball's discount factor was squared (:454)
+enum : int { RS_ELIMINATED, RS_KEY, RS_BALL, RS_INVALID };  // reward scheme columns
 
 constexpr int H_STEP = 0, H_EPISODE = 4, H_FLAGS = 8, H_META = 12, H_ROWS = 16;
 constexpr uint32_t LAYOUT_STRIDE = 7919;  // layout of episode k of env g: (g + 7919 k) mod N
@@ -94,6 +102,9 @@ struct LdsMap {
     int oterm;  // [ET][A]   u8  terminated as seen by gen_obs
     int flag;   // [ET][4]   u8  truncated, will-reset, number of log entries, unused
     int R;      // [ET]      f64 _reward() of this step
+    int racc;   // [ET][A]   f64 rewards of this step               } CompetativeRedBlueDoor
+    int pxy;    // [ET][A]   u16 positions after the post-step hook } environments only
+    int log2;   // [ET][A]   u32 cells cleared by the post-step hook}
     int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
     int grid;   // [NE][GS]      grids of the sub-tile being observed
     int img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
@@ -121,6 +132,10 @@ struct KParams {
     __host__ __device__ bool walled() const { return (bits >> 20) & 1; }  // every grid is ringed by (2,5,0) walls
     __host__ __device__ bool stream_out() const { return (bits >> 21) & 1; }     // non-temporal stores of images
     __host__ __device__ bool stream_onehot() const { return (bits >> 22) & 1; }  // ... of one-hot images
+    // CompetativeRedBlueDoorEnvV3: the low kind bits then read MG_KIND_EMPTY (no other hook runs)
+    __host__ __device__ bool comp() const { return (bits >> 23) & 1; }
+    __host__ __device__ bool death_match() const { return (bits >> 24) & 1; }
+    __host__ __device__ bool per_agent() const { return (bits >> 25) & 1; }  // dtde_step rather than ctce_step
     int max_steps;
     int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
     uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
@@ -134,6 +149,7 @@ struct KParams {
     const uint8_t *pool_hdr;
     const uint8_t *pool_grid;
     int64_t *stats;  // [64][MG_NUM_STATS] shards
+    const double *schemes;  // [A][4] reward schemes (CompetativeRedBlueDoor only)
     // inputs
     const uint8_t *actions;
     const uint8_t *order;
@@ -298,6 +314,7 @@ struct ActEval {
     uint32_t bits;  // EV_*
 };
 
+template <bool COMP = false>
 __device__ __forceinline__ ActEval eval_action(const KParams &p, uint2 r0, uint32_t w, int act, uint32_t flags,
                                                uint32_t blue_xy) {
     ActEval e;
@@ -315,7 +332,11 @@ __device__ __forceinline__ ActEval eval_action(const KParams &p, uint2 r0, uint3
     e.ci = fx * p.H() + fy;
     e.w = w;
     const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
-    const int ct = r0.y & 0xFF, cc = (r0.y >> 8) & 0xFF, cs = (r0.y >> 16) & 0xFF;
+    const int ct = r0.y & 0xFF, cc = (r0.y >> 8) & 0xFF;
+    int cs = (r0.y >> 16) & 0xFF;
+    // CompetativeRedBlueDoor: a dropped object takes the OBJECT's state (grid.py:91-95), and a key that has paid its
+    // pickup reward is "picked up" whatever the copy in the agent row says (competative_red_blue_door.py:434-435)
+    if (COMP && ct == T_KEY && (cc == C_RED || cc == C_BLUE) && ((flags >> (cc >> 1)) & FLAG_KEY_USED)) cs = S_PICKEDUP;
     const bool blue = p.kind() == MG_KIND_REDBLUEDOORS && e.fxy == blue_xy;
     // state of the world OBJECT: equals the cell except for the blue door re-closed by
     // redbluedoors.py:185 without a grid.update
@@ -323,7 +344,11 @@ __device__ __forceinline__ ActEval eval_action(const KParams &p, uint2 r0, uint3
     const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA || (t == T_DOOR && so == S_OPEN);
     const bool fwd = on_cell && act == ACT_FORWARD && can_overlap;                  // base.py:479-483
     const bool drop = on_cell && act == ACT_DROP && ct != T_EMPTY && t == T_EMPTY;  // base.py:507-511
-    const bool pk = on_cell && act == ACT_PICKUP && (t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY;  // :497-504
+    const int my_color = r0.y >> 24;
+    // competative_red_blue_door.py:573-577: an agent picks up its own colour's key and other colours' balls only
+    const bool pickable = COMP ? ((t == T_KEY && c == my_color) || (t == T_BALL && c != my_color))
+                                   : (t == T_KEY || t == T_BALL || t == T_BOX);
+    const bool pk = on_cell && act == ACT_PICKUP && pickable && ct == T_EMPTY;  // :497-504
     const bool door = on_cell && act == ACT_TOGGLE && t == T_DOOR;  // Door.toggle, world_object.py:456-472
     const bool unlock = door && so == S_LOCKED && ct == T_KEY && cc == c;
     const bool flip = door && so != S_LOCKED;
@@ -679,6 +704,7 @@ __device__ __forceinline__ void store_bytes(uint8_t *ptr, uint64_t w, int A) {
 
 // Same contract as act_env; `actw` / `ordw` hold the A action and order bytes (ordw is ignored when
 // the order is drawn on the device).
+template <bool COMP>
 __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env, uint64_t actw, uint64_t ordw) {
     const int A = p.A(), H = p.H();
     uint8_t *h = lds + p.o.hdr + slot * p.HS;
@@ -710,8 +736,10 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             const uint32_t key = order_key(p, env, h0.y, step);
             ordw = 0x0706050403020100ull;
             uint32_t word = 0;
+            // (CompetativeRedBlueDoor agents act in the order of the caller's actions dict, never a drawn one:
+            // without an order they act in index order)
 #pragma unroll 1
-            for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+            for (int k = COMP ? 0 : A - 1, f = 0; k > 0; --k, ++f) {
                 const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
                 const uint64_t d = byte_of(ordw, k) ^ byte_of(ordw, j);
                 ordw ^= (d << (8 * k)) ^ (d << (8 * j));
@@ -737,7 +765,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                 const uint32_t e = log[j];
                 if ((e & 0xFFFF) == ci0) w = e >> 16;
             }
-            ActEval ev = eval_action(p, r0, w, byte_of(actw, i), flags, blue_xy);
+            ActEval ev = eval_action<COMP>(p, r0, w, byte_of(actw, i), flags, blue_xy);
             bool occupied = false;  // base.py:485,512: every agent counts, terminated ones included
             if (needs_occupancy(p, ev))
 #pragma unroll 1
@@ -766,7 +794,136 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     // "toggle" has neither moved nor turned, so its header entry still names the cell in front of it.
     bool term_all = false;  // a hook terminated every agent
     uint64_t term_some = 0; // a hook terminated these agents (mode "all")
-    if (rbd) {  // redbluedoors.py:176-185
+    double paid_sum = 0.0;  // CompetativeRedBlueDoor: sum of this step's rewards
+    int comp_cleared = 0;   // ... and the number of cells its hook cleared (`log2`)
+    if constexpr (COMP) {
+        // CompetativeRedBlueDoorEnvV3.dtde_step / ctce_step with the default handlers
+        // (multigrid/envs/competative_red_blue_door.py:319-423): for every agent, in the order of the actions dict,
+        // _handle_steps (:475-523) then _default_extra_action_handle_steps (:425-472).  gen_obs has run by now in the
+        // reference, so nothing here may show in this step's observation: positions changed by an elimination go to
+        // `pxy`, cleared cells to `log2`; the observation pass applies both after the views are taken.
+        double *racc = reinterpret_cast<double *>(lds + p.o.racc) + slot * A;
+        uint16_t *pxy = reinterpret_cast<uint16_t *>(lds + p.o.pxy) + slot * A;
+        uint32_t *log2 = reinterpret_cast<uint32_t *>(lds + p.o.log2) + slot * A;
+        const int W = p.W();
+        const uint32_t door_xy[2] = {static_cast<uint32_t>(W / 4) | (static_cast<uint32_t>(H - 2) << 8),
+                                     static_cast<uint32_t>(W / 4 + W / 2 - 1) | (1u << 8)};  // _gen_grid, :201-211
+        uint64_t xw = 0, yw = 0, moved = 0;  // positions as the hook leaves them; agents it has moved
+#pragma unroll 1
+        for (int k = 0; k < A; ++k) {
+            xw |= static_cast<uint64_t>(rows[8 * k + R_X]) << (8 * k);
+            yw |= static_cast<uint64_t>(rows[8 * k + R_Y]) << (8 * k);
+            racc[k] = byte_of(rewmw, k) ? R : 0.0;  // a goal reached in handle_actions (base.py:491-492)
+        }
+        uint64_t iterm = termw;  // agent.terminated
+        if (p.per_agent() && termw != 0 && termw != ones) toutw = 0;  // :375-378: some but not all -> nobody
+        uint32_t ball_n = h0.w & 0xFFFF;  // meta[0], meta[1]
+        int n2 = 0;
+        auto succeed = [&](int k) {  // on_success(agent k, reward, terminated), base.py:535-562
+            if (p.succ_any()) { iterm = ones; toutw = ones; }
+            else { iterm |= 1ull << (8 * k); toutw |= 1ull << (8 * k); }
+            if (p.joint()) { for (int j = 0; j < A; ++j) racc[j] = R; }
+            else racc[k] = R;
+        };
+#pragma unroll 1
+        for (int n = 0; n < A; ++n) {
+            const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
+            const int act = byte_of(actw, i);
+            if (act != ACT_TOGGLE && act != ACT_PICKUP) continue;
+            const uint32_t my_color = rows[8 * i + R_COLOR];
+            const uint32_t me = byte_of(xw, i) | (byte_of(yw, i) << 8) | (static_cast<uint32_t>(rows[8 * i + R_DIR]) << 16);
+            const uint32_t fxy = front_xy(me);
+            if (act == ACT_TOGGLE) {
+                // the cell in front as it is now; an agent the hook has just moved faces a cell of a side room
+                uint32_t w = fcv[i];
+                const uint32_t ci = front_index(p, me);
+                const bool was_moved = byte_of(moved, i) != 0;
+#pragma unroll 1
+                for (int j = 0; j < nlog; ++j) {
+                    const uint32_t e = log[j];
+                    if ((e & 0xFFFF) == ci) w = e >> 16;
+                }
+#pragma unroll 1
+                for (int j = 0; j < n2; ++j)
+                    if ((log2[j] & 0xFFFF) == ci) w = CELL_EMPTY;
+                if (was_moved) w = CELL_EMPTY;
+                int victim = -1;  // :479-481: the last opponent standing in front
+#pragma unroll 1
+                for (int k = 0; k < A; ++k)
+                    if ((byte_of(xw, k) | (byte_of(yw, k) << 8)) == fxy && rows[8 * k + R_COLOR] != my_color) victim = k;
+                // the two door OBJECTS: open once orphaned, else as their cells read
+                bool door_open = false;
+#pragma unroll 1
+                for (int d = 0; d < 2; ++d) {
+                    uint32_t wd = fcv[A + d];
+                    const uint32_t cd = (door_xy[d] & 0xFF) * H + (door_xy[d] >> 8);
+#pragma unroll 1
+                    for (int j = 0; j < nlog; ++j) {
+                        const uint32_t e = log[j];
+                        if ((e & 0xFFFF) == cd) wd = e >> 16;
+                    }
+                    door_open |= (flags & (FLAG_DOOR_GONE << d)) || ((wd & 15) == T_DOOR && ((wd >> 4) & 15) == S_OPEN);
+                }
+                const bool at_door = (fxy == door_xy[0] && !(flags & FLAG_DOOR_GONE)) ||
+                                     (fxy == door_xy[1] && !(flags & (FLAG_DOOR_GONE << 1)));
+                if (victim < 0) {
+                    if (at_door && (w & 15) == T_DOOR && door_open && ((w >> 8) & 127) == my_color) {  // :484-492
+#pragma unroll 1
+                        for (int k = 0; k < A; ++k)
+                            if (rows[8 * k + R_COLOR] == my_color && !byte_of(iterm, k)) succeed(k);
+                    }
+                } else if (p.death_match()) {  // :498-523
+                    if (!p.fail_any()) iterm |= 1ull << (8 * victim);  // on_failure without a terminations dict
+                    if (at_door && (w & 15) == T_DOOR) flags |= fxy == door_xy[0] ? FLAG_DOOR_GONE : (FLAG_DOOR_GONE << 1);
+                    log2[n2++] = ci | (CELL_EMPTY << 16);  // grid.set(*fwd_obj.pos, None), :503
+                    const bool blue = rows[8 * victim + R_COLOR] == C_BLUE;  // :504-506
+                    xw = (xw & ~(0xFFull << (8 * victim))) | (static_cast<uint64_t>(blue ? 13 : 2) << (8 * victim));
+                    yw = (yw & ~(0xFFull << (8 * victim))) | (2ull << (8 * victim));
+                    moved |= 1ull << (8 * victim);
+                    racc[i] += p.schemes[4 * i + RS_ELIMINATED];
+                    racc[victim] -= 1.0;
+                    bool all_gone = true;  // :511-517
+#pragma unroll 1
+                    for (int k = 0; k < A; ++k) all_gone &= rows[8 * k + R_COLOR] == my_color || byte_of(iterm, k) != 0;
+                    if (all_gone) {
+#pragma unroll 1
+                        for (int k = 0; k < A; ++k)
+                            if (rows[8 * k + R_COLOR] == my_color && !byte_of(iterm, k)) succeed(k);
+                    }
+                }
+            } else {  // pickup: _default_extra_action_handle_steps, :425-472
+                const uint32_t carry = *reinterpret_cast<const uint32_t *>(rows + 8 * i + 4);  // ct cc cs color
+                const uint32_t ct = carry & 0xFF, cc = (carry >> 8) & 0xFF;
+                uint32_t cs = (carry >> 16) & 0xFF;
+                const bool rb = cc == C_RED || cc == C_BLUE;
+                if (ct == T_KEY && rb && ((flags >> (cc >> 1)) & FLAG_KEY_USED)) cs = S_PICKEDUP;
+                // Ball(color="blue") starts next to the red door, Ball(color="red") next to the blue door (:230-232)
+                const uint32_t init_xy = cc == C_RED ? door_xy[1] - 1 : door_xy[0] + 1;
+                if (ct == T_KEY && cs == S_AVAILABLE && cc == my_color) {  // :428-436
+                    if (rb) flags |= FLAG_KEY_USED << (cc >> 1);
+                    racc[i] += p.schemes[4 * i + RS_KEY];
+                } else if (ct == T_BALL && rb && cc != my_color && fxy == init_xy) {  // :445-454
+                    const int sh = 8 * (cc >> 1), cnt = (ball_n >> sh) & 0xFF;
+                    double d = 0.9;  // Ball.__new__ default, world_object.py:583
+#pragma unroll 1
+                    for (int j = 0; j < cnt; ++j) d *= d;
+                    racc[i] += p.schemes[4 * i + RS_BALL] * d;
+                    if (cnt < 255) ball_n += 1u << sh;
+                } else {
+                    racc[i] -= p.schemes[4 * i + RS_INVALID];  // :470-472
+                }
+            }
+        }
+#pragma unroll 1
+        for (int k = 0; k < A; ++k) {
+            pxy[k] = static_cast<uint16_t>(byte_of(xw, k) | (byte_of(yw, k) << 8));
+            if (byte_of(iterm, k)) rows[8 * k + R_TERM] = 1;
+            paid_sum += racc[k];
+        }
+        h[H_META] = static_cast<uint8_t>(ball_n);
+        h[H_META + 1] = static_cast<uint8_t>(ball_n >> 8);
+        comp_cleared = n2;
+    } else if (rbd) {  // redbluedoors.py:176-185
 #pragma unroll 1
         for (int i = 0; i < A; ++i) {
             if (byte_of(actw, i) != ACT_TOGGLE) continue;
@@ -843,7 +1000,8 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 
     const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
     *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * slot) =
-        (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
+        (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16) |
+        (static_cast<uint32_t>(comp_cleared) << 24);
 
     // episode statistics: touched only when something happened (rare)
     int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
@@ -852,9 +1010,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
         atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
     }
-    if (paid != 0)
+    if (COMP ? paid_sum != 0.0 : paid != 0)
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
-                  static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
+                  static_cast<unsigned long long>(static_cast<long long>((COMP ? paid_sum : paid * R) * 16777216.0)));
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset) {
@@ -862,6 +1020,11 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 #pragma unroll 1
         for (int j = 0; j < nlog; ++j) {
             const uint32_t e = log[j];
+            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+        }
+#pragma unroll 1
+        for (int j = 0; j < comp_cleared; ++j) {
+            const uint32_t e = reinterpret_cast<const uint32_t *>(lds + p.o.log2)[slot * A + j];
             gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
         }
     }
@@ -1257,13 +1420,17 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
 // MULTI: the launch takes p.T consecutive steps (mg_step_n).  Header blocks AND the grids of all ET environments
 // then stay in LDS from the first step to the last; per step only actions come in and observations, rewards and
 // flags go out (plus the few grid cells a step changes, which still go to HBM at once, and restarts from the pool).
-template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false>
+// COMP: a step of CompetativeRedBlueDoor environments (their hook runs after gen_obs and moves agents).
+template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false, bool COMP = false>
 #ifndef MG_KERNEL_ATTR
 #define MG_KERNEL_ATTR
 #endif
-// tuning builds: wavefronts per SIMD the register allocation must leave room for (single-step / multi-step kernels)
+// Wavefronts per SIMD the register allocation must leave room for.  The single-step kernels of see-through
+// environments sit right at 128 registers (four wavefronts; measured 7-10 % faster than three): the hint keeps them
+// there without a spill when an unrelated change nudges the allocator.  The others need 139-170 registers and lose
+// more to spills than a fourth wavefront gives (measured), so they are left alone.  Tuning builds can override.
 #ifndef MG_WAVES_SINGLE
-#define MG_WAVES_SINGLE 1
+#define MG_WAVES_SINGLE ((SEE && !OH && !COMP && MODE == MODE_STEP) ? 4 : 1)
 #endif
 #ifndef MG_WAVES_MULTI
 #define MG_WAVES_MULTI 1
@@ -1272,6 +1439,7 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR
 __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))) void mg_tile_kernel(const KParams p0) {
     extern __shared__ __align__(16) uint8_t lds[];
     static_assert(!MULTI || (MODE == MODE_STEP && !OH), "the multi-step kernel steps and writes compact images");
+    static_assert(!COMP || (MODE == MODE_STEP && SMALLA && !OH && !WALLED), "CompetativeRedBlueDoor steps: one variant");
     // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
     typename std::conditional<MULTI, KParams, const KParams &>::type p = p0;
     constexpr int IMG = 3 * V * V;  // bytes per agent image
@@ -1477,7 +1645,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         wave_sync();
     }
     if (MODE == MODE_STEP) {
-        if (A >= PARALLEL_ACT_MIN_AGENTS) {
+        if (A >= PARALLEL_ACT_MIN_AGENTS && !COMP) {
 #pragma unroll 1
             for (int s0 = 0; s0 < net; s0 += NE) act_lanes(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
         } else if (lane < net) {
@@ -1492,7 +1660,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (__ballot(lane < net && !(*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * lane) & ACT_FINISHED)) != 0 &&
             lane < net) {
             if constexpr (small)
-                act_env_small(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
+                act_env_small<COMP>(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
                               p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
             else
                 act_env(p, lds, lane, e0 + lane);
@@ -1522,8 +1690,12 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                     reload_env(p, lds, s, env, layout, episode, lane);
                     if (lane == 0) lsrc[s] = layout;
                     if (lane == 0) lds[p.o.flag + 4 * s + 2] = 0;  // the fresh grid takes no patches
+                    if (lane == 0) lds[p.o.flag + 4 * s + 3] = 0;
                     wave_sync();
                     if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HS + H_ROWS + 8 * lane + R_TERM];
+                    if (COMP && lane < A)  // nothing of the hook is left to apply: the agents stand where the layout puts them
+                        reinterpret_cast<uint16_t *>(lds + p.o.pxy)[s * A + lane] =
+                            *reinterpret_cast<const uint16_t *>(lds + p.o.hdr + s * p.HS + H_ROWS + 8 * lane);
                 }
                 wave_sync();
             }
@@ -1575,32 +1747,43 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 my_row = *reinterpret_cast<const uint2 *>(my_hdr + H_ROWS + 8 * my_agent);
                 my_gone = lds[p.o.oterm + (s0 + my_slot) * A + my_agent] != 0;
             }
-            // front cells for the NEXT launch, taken before agents are drawn into the grid
-            if (MODE != MODE_OBS) {
+            // Front cells for the NEXT launch, taken while no agent is drawn into the grid.  A CompetativeRedBlueDoor
+            // step takes them after the views instead: its hook moves agents and clears cells, and none of that may
+            // show in this step's observation.
+            constexpr bool comp_step = COMP;
+            auto refresh_front = [&](uint32_t row_x) {
                 if (mine) {
-                    const uint32_t ci = front_index(p, my_row.x);
+                    const uint32_t fi = front_index(p, row_x);
                     reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HS + p.HFC)[my_agent] =
-                        ci == FC_NONE ? static_cast<uint16_t>(0) : my_grid[ci];
+                        fi == FC_NONE ? static_cast<uint16_t>(0) : my_grid[fi];
                 }
-                if (p.kind() == MG_KIND_REDBLUEDOORS && lane < ns && ((sub_mask >> lane) & 1)) {
+                // (a step of CompetativeRedBlueDoor environments is always a COMP launch)
+                const bool comp_env = COMP || (MODE != MODE_STEP && p.comp());
+                if ((p.kind() == MG_KIND_REDBLUEDOORS || comp_env) && lane < ns && ((sub_mask >> lane) & 1)) {
                     uint8_t *h = lds + p.o.hdr + (s0 + lane) * p.HS;
-                    const uint32_t meta = *reinterpret_cast<const uint32_t *>(h + H_META);
+                    uint32_t meta = *reinterpret_cast<const uint32_t *>(h + H_META);
+                    if (comp_env)  // the doors of competative_red_blue_door.py:201-211 never move
+                        meta = static_cast<uint32_t>(p.W() / 4) | (static_cast<uint32_t>(p.H() - 2) << 8) |
+                               (static_cast<uint32_t>(p.W() / 4 + p.W() / 2 - 1) << 16) | (1u << 24);
                     const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
                     const uint32_t last = static_cast<uint32_t>(p.W() * p.H() - 1);
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A] = g[min((meta & 0xFF) * p.H() + ((meta >> 8) & 0xFF), last)];
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A + 1] = g[min(((meta >> 16) & 0xFF) * p.H() + (meta >> 24), last)];
                 }
+            };
+            if (MODE != MODE_OBS && !comp_step) {
+                refresh_front(my_row.x);
                 wave_sync();
             }
             if (s0 == 0) MG_STAMP(5);
             // Draw every live agent into the grid copy; where several share a cell the highest index
             // shows (multigrid/utils/obs.py:157-165: index order, later agents overwrite; single-agent
             // environments draw nothing, obs.py:166-167).
+            bool draw = false;  // this lane's agent is drawn at cell `ci`, which held `under`
+            uint32_t ci = 0, under = 0;
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 8))
 #endif
-            bool draw = false;  // this lane's agent is drawn at cell `ci`, which held `under`
-            uint32_t ci = 0, under = 0;
             if (want_img && A > 1) {
                 // LDS writes of one wavefront land in program order, so drawing the agents index by index
                 // leaves the highest one on a shared cell without looking at the other agents at all
@@ -1614,7 +1797,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 }
                 // the multi-step kernel keeps its grids: every lane notes what lies under its agent before the
                 // first agent is drawn, and puts it back once the views have been taken
-                if (MULTI && draw) under = my_grid[ci];
+                if ((MULTI || comp_step) && draw) under = my_grid[ci];
 #pragma unroll 1
                 for (int k = 0; k < A; ++k) {
                     if (draw && my_agent == k) my_grid[ci] = static_cast<uint16_t>(val);
@@ -1634,8 +1817,27 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (want_img && mine)
                 observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + (gslot0 + my_slot) * (p.GS + 16), px);
             wave_sync();
-            if (MULTI) {
+            if (MULTI || comp_step) {
                 if (draw) my_grid[ci] = static_cast<uint16_t>(under);
+                wave_sync();
+            }
+            if (comp_step) {
+                // what the hook did after gen_obs: cells cleared under eliminated agents, agents moved away
+                if (lane < ns && ((sub_mask >> lane) & 1)) {
+                    const uint32_t *log2 = reinterpret_cast<const uint32_t *>(lds + p.o.log2) + (s0 + lane) * A;
+                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
+                    const int n2 = lds[p.o.flag + 4 * (s0 + lane) + 3];
+                    for (int j = 0; j < n2; ++j) g[log2[j] & 0xFFFF] = static_cast<uint16_t>(log2[j] >> 16);
+                }
+                uint32_t row_x = my_row.x;
+                if (mine) {
+                    const uint32_t xy = reinterpret_cast<const uint16_t *>(lds + p.o.pxy)[(s0 + my_slot) * A + my_agent];
+                    row_x = (row_x & 0xFFFF0000u) | xy;
+                    *reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HS + H_ROWS + 8 * my_agent) =
+                        static_cast<uint16_t>(xy);
+                }
+                wave_sync();
+                refresh_front(row_x);
                 wave_sync();
             }
             // The next sub-tile's grids set out now, travel while this sub-tile's images are stored and
@@ -1773,7 +1975,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (p.direction) p.direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
         if (MODE == MODE_STEP) {
             if (p.reward)
-                p.reward[o] = static_cast<float>(reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]));
+                p.reward[o] = COMP ? static_cast<float>(reinterpret_cast<const double *>(lds + p.o.racc)[s])
+                                       : static_cast<float>(reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]));
             if (p.terminated) p.terminated[o] = lds[p.o.tout + s];
             if (p.truncated) p.truncated[o] = lds[p.o.flag + 4 * slot];
         }
@@ -1912,6 +2115,8 @@ __global__ void mg_refresh_front_kernel(KParams p) {
         } else if (p.kind() == MG_KIND_REDBLUEDOORS) {
             const int mx = h[H_META + 2 * (k - p.A())], my = h[H_META + 2 * (k - p.A()) + 1];
             ci = min(static_cast<uint32_t>(mx * p.H() + my), static_cast<uint32_t>(p.W() * p.H() - 1));
+        } else if (p.comp()) {  // the doors of competative_red_blue_door.py:201-211
+            ci = k == p.A() ? (p.W() / 4) * p.H() + p.H() - 2 : (p.W() / 4 + p.W() / 2 - 1) * p.H() + 1;
         }
         reinterpret_cast<uint16_t *>(h + p.HFC)[k] = ci == FC_NONE ? static_cast<uint16_t>(0) : g[ci];
     }
@@ -2182,6 +2387,7 @@ struct MgEnv {
     size_t lds_multi = 0;  // 0: the configuration does not fit, mg_step_n falls back to one launch per step
     bool multi_enabled = true;
     uint8_t *hdr = nullptr, *grid = nullptr, *pool_hdr = nullptr, *pool_grid = nullptr;
+    double *schemes = nullptr;  // [A][4], CompetativeRedBlueDoor only
     int64_t *stats = nullptr;
     int num_layouts = 0;
     bool reset_done = false;
@@ -2217,6 +2423,25 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int V, int MODE, bool WALLED, bool OH, bool MULTI = false>
+void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s);
+
+// steps of CompetativeRedBlueDoor environments (at most 8 agents, compact images, general border code)
+template <int V, bool MULTI>
+void launch_comp(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
+    const dim3 grid(h->num_tiles), block(64);
+    KParams kp = kp_in;
+    size_t lds = h->lds_bytes;
+    if (MULTI) {
+        kp.o = h->o_multi;
+        lds = h->lds_multi;
+    }
+    if (h->cfg.see_through_walls)
+        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE_STEP, true, false, false, MULTI, true>), grid, block, lds, s, kp);
+    else
+        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE_STEP, true, false, false, MULTI, true>), grid, block, lds, s, kp);
+}
+
+template <int V, int MODE, bool WALLED, bool OH, bool MULTI>
 void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
     const dim3 grid(h->num_tiles), block(64);
     KParams kp = kp_in;
@@ -2241,6 +2466,10 @@ void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
 template <int V, int MODE>
 void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
     if constexpr (MODE == MODE_STEP) {
+        if (kp.comp()) {
+            if (kp.T > 1) launch_comp<V, true>(h, kp, s); else launch_comp<V, false>(h, kp, s);
+            return;
+        }
         if (kp.T > 1) {  // mg_step_n: one launch for T steps (never with one-hot images)
             if (kp.walled())
                 launch_vmw<V, MODE, true, false, true>(h, kp, s);
@@ -2324,7 +2553,15 @@ namespace {
 // Everything mg_create derives from the configuration without touching a device: validation, packed
 // kernel parameters, tile shape, LDS map.  Errors go to the creation-error text.
 int configure(MgEnv *h, const MgConfig &c) {
-    if (c.kind < 0 || c.kind > MG_KIND_LOCKEDHALLWAY) return fail(nullptr, MG_EINVAL, "unknown kind %d", c.kind);
+    if (c.kind < 0 || c.kind > MG_KIND_COMPETITIVE) return fail(nullptr, MG_EINVAL, "unknown kind %d", c.kind);
+    if (c.kind == MG_KIND_COMPETITIVE) {
+        if (c.num_agents > 8) return fail(nullptr, MG_EINVAL, "CompetativeRedBlueDoor supports at most 8 agents, got %d", c.num_agents);
+        if (c.width < 8 || c.height < 4 || c.width % 4 != 0)
+            return fail(nullptr, MG_EINVAL, "CompetativeRedBlueDoor needs a grid of 2 * size x size cells, got %dx%d", c.width, c.height);
+        // eliminated agents are put at (13, 2) / (2, 2) whatever the size (competative_red_blue_door.py:504-506)
+        if (c.death_match && (c.width != 16 || c.height != 8))
+            return fail(nullptr, MG_EINVAL, "CompetativeRedBlueDoor with death_match needs the 16x8 grid (size 8), got %dx%d", c.width, c.height);
+    }
     if (c.width < 3 || c.height < 3 || c.width > 255 || c.height > 255 || c.width * c.height > 4096)
         return fail(nullptr, MG_EINVAL, "grid %dx%d not supported (3..255 per side, at most 4096 cells)", c.width,
                     c.height);
@@ -2343,7 +2580,10 @@ int configure(MgEnv *h, const MgConfig &c) {
     KParams &kp = h->kp;
     kp.geo = static_cast<uint32_t>(c.width) | (static_cast<uint32_t>(c.height) << 8) |
              (static_cast<uint32_t>(c.num_agents) << 16);
-    kp.bits = static_cast<uint32_t>(c.kind) | (c.allow_agent_overlap ? 4u : 0u) | (c.joint_reward ? 8u : 0u) |
+    // (CompetativeRedBlueDoor: low kind bits 0, its own bit 23, then death_match and per_agent_outputs)
+    kp.bits = (c.kind == MG_KIND_COMPETITIVE ? ((1u << 23) | (c.death_match ? 1u << 24 : 0u) | (c.per_agent_outputs ? 1u << 25 : 0u))
+                                             : static_cast<uint32_t>(c.kind)) |
+              (c.allow_agent_overlap ? 4u : 0u) | (c.joint_reward ? 8u : 0u) |
               (c.success_any ? 16u : 0u) | (c.failure_any ? 32u : 0u) | (static_cast<uint32_t>(c.autoreset) << 6) |
               (static_cast<uint32_t>(c.num_rooms & 15) << 8);
     kp.max_steps = c.max_steps;
@@ -2373,6 +2613,11 @@ int configure(MgEnv *h, const MgConfig &c) {
         kp.o.flag = take(4 * et);
         kp.o.R = take(8 * et);
         kp.o.src = take(4 * et);
+        if (c.kind == MG_KIND_COMPETITIVE) {
+            kp.o.racc = take(8 * et * c.num_agents);
+            kp.o.pxy = take(2 * et * c.num_agents);
+            kp.o.log2 = take(4 * et * c.num_agents);
+        }
         if (multi) {  // every grid of the tile stays; images are staged beside them
             kp.o.grid = take(et * (kp.GS + 16));
             kp.o.stage = take(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np));
@@ -2461,7 +2706,16 @@ int mg_create(const MgConfig *cfg, MgHandle *out) {
         mg_destroy(h);
         return MG_EHIP;
     }
-    kp.hdr = h->hdr; kp.grid = h->grid; kp.stats = h->stats;
+    if (e == hipSuccess && c.kind == MG_KIND_COMPETITIVE) {  // every reward zero until mg_set_reward_schemes
+        e = hipMalloc(&h->schemes, sizeof(double) * 4 * c.num_agents);
+        if (e == hipSuccess) e = hipMemset(h->schemes, 0, sizeof(double) * 4 * c.num_agents);
+        if (e != hipSuccess) {
+            fail(nullptr, MG_EHIP, "mg_create: %s", hipGetErrorString(e));
+            mg_destroy(h);
+            return MG_EHIP;
+        }
+    }
+    kp.hdr = h->hdr; kp.grid = h->grid; kp.stats = h->stats; kp.schemes = h->schemes;
     *out = h;
     return MG_OK;
 }
@@ -2474,6 +2728,7 @@ int mg_destroy(MgHandle h) {
     if (h->pool_hdr) (void)hipFree(h->pool_hdr);
     if (h->pool_grid) (void)hipFree(h->pool_grid);
     if (h->stats) (void)hipFree(h->stats);
+    if (h->schemes) (void)hipFree(h->schemes);
     delete h;
     return MG_OK;
 }
@@ -2529,6 +2784,10 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
                 return fail(h, MG_EINVAL, "layout %d: meta does not name a red door at (%d,%d) and a blue door at (%d,%d)", l,
                             m[0], m[1], m[2], m[3]);
         }
+        if (kp.comp()) {  // the doors of competative_red_blue_door.py:201-211
+            fc[A] = gd[(kp.W() / 4) * kp.H() + kp.H() - 2];
+            fc[A + 1] = gd[(kp.W() / 4 + kp.W() / 2 - 1) * kp.H() + 1];
+        }
     }
     MG_HIP(h, hipSetDevice(h->cfg.device));
     MG_HIP(h, hipDeviceSynchronize());
@@ -2547,9 +2806,20 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
     return MG_OK;
 }
 
+int mg_set_reward_schemes(MgHandle h, const double *schemes) {
+    if (!h) return MG_EINVAL;
+    if (!schemes) return fail(h, MG_EINVAL, "mg_set_reward_schemes: null pointer");
+    if (!h->schemes) return fail(h, MG_EINVAL, "mg_set_reward_schemes: only MG_KIND_COMPETITIVE has reward schemes");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    MG_HIP(h, hipDeviceSynchronize());
+    MG_HIP(h, hipMemcpy(h->schemes, schemes, sizeof(double) * 4 * h->cfg.num_agents, hipMemcpyHostToDevice));
+    return MG_OK;
+}
+
 int mg_generate_layouts(MgHandle h, const MgLayoutSpec *spec, int32_t n, uint64_t seed) {
     if (!h) return MG_EINVAL;
     if (!spec || n < 1) return fail(h, MG_EINVAL, "mg_generate_layouts: null spec or n < 1");
+    if (h->kp.comp()) return fail(h, MG_EINVAL, "mg_generate_layouts: not available for MG_KIND_COMPETITIVE (upload host layouts)");
     const KParams &kp = h->kp;
     const int W = kp.W(), H = kp.H(), kind = kp.kind();
     // the grid size must be the one the family builds
@@ -2627,6 +2897,8 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
     if (!h) return MG_EINVAL;
     if (!actions_dev) return fail(h, MG_EINVAL, "mg_step: actions_dev is null");
     if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_step: onehot_dev must be 8-byte aligned");
+    if (h->kp.comp() && out && out->onehot_dev)
+        return fail(h, MG_EINVAL, "mg_step: one-hot images are not written for MG_KIND_COMPETITIVE (use mg_gen_obs)");
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_step: call mg_reset (or mg_set_state) first");
     if (h->cfg.autoreset != MG_AUTORESET_NONE && h->num_layouts < 1)
         return fail(h, MG_ESTATE, "mg_step: autoreset needs uploaded layouts");

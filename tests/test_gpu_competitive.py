@@ -1,0 +1,174 @@
+"""CompetativeRedBlueDoorEnvV3 (MG_KIND_COMPETITIVE) at batch sizes, against the C oracle: every registered team
+shape, death match on and off, all auto-reset modes, single launches and the multi-step launch."""
+import numpy as np
+import pytest
+
+from multigrid_amd import envs, layouts
+from test_gpu_batch import compare, compare_state, expected_layout
+
+pytestmark = pytest.mark.gpu
+
+V3 = "MultiGrid-CompetativeRedBlueDoor-v3-"
+PICKY = np.array([0.10, 0.10, 0.25, 0.22, 0.08, 0.23, 0.02])
+
+
+def make(name, e, n_layouts=48, **kw):
+    from multigrid_amd.batched import BatchedMultiGrid
+    from oracle.coracle import BatchOracle
+    extra = {k: kw.pop(k) for k in list(kw) if k in ("autoreset", "env_id_offset", "seed")}
+    spec, gen = envs.make_spec(V3 + name, **kw)
+    pool = layouts.make_pool(gen, n_layouts, seed0=5)
+    env = BatchedMultiGrid(spec, e, device=0, **extra)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    return spec, pool, env, BatchOracle(spec, e)
+
+
+def crowd(ora, rng, frac=0.5):
+    """Move the agents of some environments next to each other, to the keys and in front of the doors, so that
+    eliminations, key pickups and door openings happen at once (the start positions are far apart)."""
+    e, a = ora.agents.shape[0], ora.agents.shape[1]
+    w, h = ora.grid.shape[1], ora.grid.shape[2]
+    for env in np.nonzero(rng.random(e) < frac)[0]:
+        free = [(x, y) for x in range(w // 4 + 1, w // 4 + w // 2 - 1) for y in range(1, h - 1) if ora.grid[env, x, y, 0] == 1]
+        rng.shuffle(free)
+        x, y = free[0]
+        cells = [(x + dx, y + dy) for dx in (0, 1, -1) for dy in (0, 1, -1)
+                 if ora.grid[env, x + dx, y + dy, 0] == 1][:a]
+        for k, c in enumerate(cells):
+            ora.agents[env, k, 0:2] = c
+            ora.agents[env, k, 2] = rng.integers(4)
+        if rng.random() < 0.5:   # hand every agent its team's key if it lies around
+            for k in range(a):
+                col = ora.agents[env, k, 7]
+                pos = np.argwhere((ora.grid[env, :, :, 0] == 5) & (ora.grid[env, :, :, 1] == col))
+                if len(pos) and ora.agents[env, k, 4] == 1:
+                    ora.agents[env, k, 4:7] = ora.grid[env, pos[0][0], pos[0][1]]
+                    ora.grid[env, pos[0][0], pos[0][1]] = (1, 0, 0)
+                    if col == 0:
+                        ora.agents[env, k, 0:3] = (w // 4 + 1, h - 2, 2)
+                    elif col == 2:
+                        ora.agents[env, k, 0:3] = (w // 4 + w // 2 - 2, 1, 0)
+                    break
+
+
+CASES = [
+    ("DTDE-1v1", {}), ("DTDE-2v2", dict(max_steps=40)), ("DTDE-2v2-Death-Match", dict(max_steps=50, agent_view_size=7)),
+    ("CTCE-2v2", dict(max_steps=40, agent_view_size=3)), ("DTDE-Red", dict(max_steps=30)),
+    ("DTDE-Red-Single-with-Obstacle", dict(max_steps=30)),
+    ("CTDE-2v2", dict(max_steps=40, success_termination_mode="all", allow_agent_overlap=True, death_match=True)),
+]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("name,kw", CASES)
+def test_competitive_against_oracle(name, kw, mode):
+    import torch
+    e = 1500
+    kw = dict(kw)
+    if name == "DTDE-1v1":
+        kw["max_steps"] = 40
+    spec, pool, env, ora = make(name, e, autoreset=mode, **kw)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(31)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    out = env.reset()
+    idx = expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    np.testing.assert_array_equal(out.image.cpu().numpy(), ora.gen_obs())
+    crowd(ora, rng)
+    env.set_state(grid=ora.grid, agents=ora.agents)
+    seen = dict(win=0, kill=0, fl=set())
+    for t in range(60):
+        actions = rng.choice(7, size=(e, a), p=PICKY).astype(np.uint8)
+        order = np.argsort(rng.random((e, a)), axis=1).astype(np.uint8)
+        give_order = t % 3 != 2
+        out = env.step(actions, order if give_order else None)   # without an order: index order
+        img, direction, rew, term, trunc = ora.step(actions, order if give_order else None)
+        img, direction = img.copy(), direction.copy()
+        seen["win"] += int((rew > 0.6).sum())
+        seen["kill"] += int((rew < -0.5).sum())
+        seen["fl"].update(np.unique(ora.flags).tolist())
+        done = term.all(axis=1) | trunc.all(axis=1)
+        if mode == 0:
+            compare(out, (img, direction, rew, term, trunc), f"{name} step {t}")
+            if done.any():
+                ids = np.nonzero(done)[0]
+                new = rng.integers(0, n_l, size=e)
+                ora.load(ids, pool[0][new[ids]], pool[1][new[ids]], pool[2][new[ids]])
+                env.reset(layout_idx=new, mask=done.astype(np.uint8))
+        else:
+            if done.any():
+                ids = np.nonzero(done)[0]
+                episode[ids] += 1
+                idx = expected_layout(ids, episode[ids], n_l)
+                ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+                if mode == 1:
+                    img[ids] = ora.gen_obs()[ids]
+                    direction[ids] = ora.agents[ids, :, 2]
+            compare(out, (img, direction, rew, term, trunc), f"{name} mode {mode} step {t}")
+        if t % 10 == 9:
+            compare_state(env, ora, f"{name} mode {mode} step {t}")
+    compare_state(env, ora, f"{name} final")
+    assert seen["win"] > 0
+    if spec["death_match"] and a > 1 and len(set(ora.agents[0, :, 7])) > 1:
+        assert seen["kill"] > 0
+    env.close()
+
+
+@pytest.mark.parametrize("name,kw,mode", [("DTDE-2v2-Death-Match", dict(max_steps=30), 1), ("DTDE-1v1", dict(max_steps=25), 2),
+                                          ("CTDE-2v2", dict(max_steps=30), 0)])
+def test_competitive_multi_step_launch(name, kw, mode):
+    import torch
+    e, t_steps = 1300, 9
+    spec, pool, env, ora = make(name, e, autoreset=mode, **kw)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(32)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    env.reset()
+    idx = expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    crowd(ora, rng)
+    env.set_state(grid=ora.grid, agents=ora.agents)
+    for call in range(3):
+        acts = rng.choice(7, size=(t_steps, e, a), p=PICKY).astype(np.uint8)
+        order = np.argsort(rng.random((t_steps, e, a)), axis=2).astype(np.uint8)
+        out = env.step_n(acts, order)
+        torch.cuda.synchronize()
+        for t in range(t_steps):
+            img, direction, rew, term, trunc = ora.step(acts[t], order[t])
+            img, direction = img.copy(), direction.copy()
+            done = term.all(axis=1) | trunc.all(axis=1)
+            if mode != 0 and done.any():
+                ids = np.nonzero(done)[0]
+                episode[ids] += 1
+                idx = expected_layout(ids, episode[ids], n_l)
+                ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+                if mode == 1:
+                    img[ids] = ora.gen_obs()[ids]
+                    direction[ids] = ora.agents[ids, :, 2]
+            where = f"{name} call {call} slice {t}"
+            np.testing.assert_array_equal(out.image[t].cpu().numpy(), img, err_msg=where + " image")
+            np.testing.assert_array_equal(out.direction[t].cpu().numpy(), direction, err_msg=where)
+            np.testing.assert_allclose(out.reward[t].cpu().numpy(), rew, rtol=0, atol=1e-6, err_msg=where + " reward")
+            np.testing.assert_array_equal(out.terminated[t].cpu().numpy(), term, err_msg=where + " terminated")
+            np.testing.assert_array_equal(out.truncated[t].cpu().numpy(), trunc, err_msg=where + " truncated")
+        compare_state(env, ora, f"{name} after call {call}")
+    env.close()
+
+
+def test_competitive_limits():
+    from multigrid_amd._lib import MgError
+    from multigrid_amd.batched import BatchedMultiGrid
+    spec, _ = envs.make_spec(V3 + "DTDE-2v2", size=6)   # eliminated agents are put at (13, 2): the 16 x 8 grid only
+    with pytest.raises(MgError, match="16x8"):
+        BatchedMultiGrid(spec, 4, device=0)
+    spec, gen = envs.make_spec(V3 + "DTDE-2v2")
+    env = BatchedMultiGrid(spec, 4, device=0, one_hot=True)
+    pool = layouts.make_pool(gen, 2)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    env.reset()
+    with pytest.raises(MgError, match="one-hot"):
+        env.step(np.zeros((4, 4), np.uint8))
+    env.close()

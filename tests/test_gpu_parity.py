@@ -41,4 +41,7 @@ def test_hip_replays_reference(name):
         np.testing.assert_array_equal(st["grid"].cpu().numpy()[live], d["post_grid"][live, t], err_msg=where + " grid")
         np.testing.assert_array_equal(st["agents"].cpu().numpy()[live], d["post_agents"][live, t],
                                       err_msg=where + " agents")
+        if "post_flags" in d:  # CompetativeRedBlueDoorEnvV3: key objects used up, doors orphaned, ball discounts
+            np.testing.assert_array_equal(st["flags"].cpu().numpy()[live], d["post_flags"][live, t], err_msg=where + " flags")
+            np.testing.assert_array_equal(st["meta"].cpu().numpy()[live], d["post_meta"][live, t], err_msg=where + " meta")
     env.close()
