@@ -196,6 +196,74 @@ class MultiGridEnv:
         return self._sim.get_state()["grid"][0].cpu().numpy().astype(np.int64)
 
 
+class CompetativeRedBlueDoorEnv(MultiGridEnv):
+    """Drop-in for ``CompetativeRedBlueDoorEnvV3`` with its default step handlers (no policy objects):
+    multigrid/envs/competative_red_blue_door.py:24.  With ``training_scheme`` "DTDE" / "CTDE" everything is keyed by
+    agent name (``"red_0"``), actions ``{name: action}`` (:372-423); with "CTCE" by team, actions
+    ``{team: [action of each team member]}``, observations ``{team: [{"agent_id", "image", "direction", "mission"}]}``,
+    rewards summed and flags and-ed per team (:319-370).  Agents act in the order of the keys of the actions dict
+    (:624-643).  The info dicts and the mission texts the reference rewrites on pickups are not reproduced (infos
+    are empty, the mission stays the first of the mission space's texts)."""
+
+    def __init__(self, name: str, device: int | str = 0, layout_rng: Optional[np.random.Generator] = None, **kwargs):
+        spec, _ = envs.make_spec(name, **kwargs)
+        if spec["kind"] != _lib.KIND_COMPETITIVE:
+            raise ValueError(f"{name} is not a CompetativeRedBlueDoor configuration")
+        self.training_scheme = spec["training_scheme"]
+        super().__init__(name, device=device, layout_rng=layout_rng, teams=kwargs.pop("teams", None), **kwargs)
+        self.agent_names = list(self.spec["agent_names"])
+        self.team_members: Dict[str, list] = {}
+        for i, n in enumerate(self.agent_names):
+            self.team_members.setdefault(n.rsplit("_", 1)[0], []).append(i)
+        self.teams = {t: len(m) for t, m in self.team_members.items()}
+
+    def _format_obs(self, obs):
+        if self.training_scheme == "CTCE":  # gen_obs, :298-309
+            return {team: [dict(obs[k], agent_id=j) for j, k in enumerate(members)]
+                    for team, members in self.team_members.items()}
+        return {self.agent_names[k]: obs[k] for k in range(self.num_agents)}  # :310-316
+
+    def reset(self, seed: Optional[int] = None, **kwargs):
+        obs, infos = super().reset(seed=seed, **kwargs)
+        return self._format_obs(obs), infos
+
+    def gen_obs(self):
+        return self._format_obs(super().gen_obs())
+
+    def step(self, actions):
+        a = self.num_agents
+        acts = np.full((1, a), 6, dtype=np.uint8)  # agents the caller leaves out do nothing ("done")
+        order = []
+        if self.training_scheme == "CTCE":  # :624-629
+            for team, team_actions in actions.items():
+                for j, act in enumerate(team_actions):
+                    k = self.team_members[team][j]
+                    acts[0, k] = int(act)
+                    order.append(k)
+        else:  # :631-641
+            for name, act in actions.items():
+                k = self.agent_names.index(name)
+                acts[0, k] = int(act)
+                order.append(k)
+        order += [k for k in range(a) if k not in order]
+        out = self._sim.step(acts, np.array([order], dtype=np.uint8))
+        self.step_count += 1
+        rew = out.reward[0].cpu().numpy().astype(np.float64)  # float32 on the device
+        term = out.terminated[0].cpu().numpy().astype(bool)
+        trunc = out.truncated[0].cpu().numpy().astype(bool)
+        self._terminated = self._sim.get_state()["agents"][0, :, 3].cpu().numpy().astype(bool)
+        obs = self._format_obs(self._obs_dict(out))
+        if self.training_scheme == "CTCE":  # :346-368
+            rewards = {t: float(sum(rew[k] for k in m)) for t, m in self.team_members.items()}
+            terminations = {t: bool(all(term[k] for k in m)) for t, m in self.team_members.items()}
+            truncations = {t: bool(all(trunc[k] for k in m)) for t, m in self.team_members.items()}
+        else:  # :408-421
+            rewards = {n: float(rew[k]) for k, n in enumerate(self.agent_names)}
+            terminations = {n: bool(term[k]) for k, n in enumerate(self.agent_names)}
+            truncations = {n: bool(trunc[k]) for k, n in enumerate(self.agent_names)}
+        return obs, rewards, terminations, truncations, {}
+
+
 class RLlibWrapper:
     """``MultiAgentEnv`` view: ``__all__`` keys added to terminations and truncations
     (multigrid/rllib/__init__.py:71-76)."""
@@ -257,4 +325,6 @@ class PettingZooWrapper:
 
 def make(name: str, **kwargs) -> MultiGridEnv:
     """``gym.make``-style constructor over the registry (multigrid/envs/__init__.py:43-625)."""
+    if envs.CONFIGURATIONS[name][0] == "competitive":
+        return CompetativeRedBlueDoorEnv(name, **kwargs)
     return MultiGridEnv(name, **kwargs)

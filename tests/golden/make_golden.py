@@ -332,7 +332,7 @@ def comp_hidden(env, keys, balls):
 
 
 def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None, script=None, extra_after_done=3,
-                       view=None):
+                       view=None, ctce=False):
     """Trajectories of CompetativeRedBlueDoorEnvV3 with its default step handlers (policies_map = {}).  The order in
     which agents act is the order of the keys of the actions dict (:633-641, :390); the harness shuffles it every step
     and records it."""
@@ -349,6 +349,18 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
         obs, _ = env.reset(seed=seed0 * 7919 + n)
         a = env.num_agents
         names = [ag.name for ag in env.agents]
+        teams = list(env.teams)  # ctce_step keys everything by team (:319-370); kept here in the order of `teams`
+        members = {tm: [env.team_index_dict[tm][j] for j in range(env.teams[tm])] for tm in teams}
+
+        def per_agent(d):  # observations of a step, by agent index
+            if ctce:
+                flat = [None] * a
+                for tm in teams:
+                    for j, k in enumerate(members[tm]):
+                        assert d[tm][j]["agent_id"] == j
+                        flat[k] = d[tm][j]
+                return flat
+            return [d[nm] for nm in names]
         keys = {str(o.color.value if hasattr(o.color, "value") else o.color): o
                 for o in env.grid.world_objects.values() if isinstance(o, Key)}
         balls = {str(o.color.value if hasattr(o.color, "value") else o.color): o
@@ -356,6 +368,7 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
         if edit is not None:
             edit(env, rng, n, keys, balls)
             obs = env.gen_obs()
+        obs = per_agent(obs)
         if spec is None:
             spec = dict(
                 kind=4, width=env.width, height=env.height, num_agents=a, max_steps=env.max_steps,
@@ -366,11 +379,13 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
                 per_agent_outputs=env.training_scheme != "CTCE",
                 reward_schemes=[[float(env.reward_schemes[nm][k]) for k in SCHEME_KEYS] for nm in names],
                 agent_names=names)
+            if ctce:
+                spec["team_members"] = [members[tm] for tm in teams]
         v = env.agents[0].view_size
         tr = dict(
             layout_grid=env.grid.state.astype(np.uint8).copy(), layout_agents=agent_rows(env),
             layout_meta=np.zeros(4, np.uint8),
-            reset_image=np.stack([obs[nm]["image"] for nm in names]).astype(np.uint8),
+            reset_image=np.stack([o["image"] for o in obs]).astype(np.uint8),
             actions=[], order=[], image=[], direction=[], reward=[], terminated=[], truncated=[], post_grid=[],
             post_agents=[], post_flags=[], post_meta=[])
         after = 0
@@ -381,17 +396,25 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
                 acts = rng.integers(0, 7, size=a)
             else:
                 acts = rng.choice(7, size=a, p=action_p)
-            order = rng.permutation(a)
-            o, r, term, trunc, _ = env.step({names[i]: int(acts[i]) for i in order})
+            if ctce:  # one list of actions per team; teams, and so their agents, act in the order of the dict
+                team_order = [teams[j] for j in rng.permutation(len(teams))]
+                order = np.array([k for tm in team_order for k in members[tm]])
+                o, r, term, trunc, _ = env.step({tm: [int(acts[k]) for k in members[tm]] for tm in team_order})
+                out_keys = teams   # rewards summed, flags and-ed per team (:346-368)
+            else:
+                order = rng.permutation(a)
+                o, r, term, trunc, _ = env.step({names[i]: int(acts[i]) for i in order})
+                out_keys = names
+            o = per_agent(o)
             tr["actions"].append(acts.astype(np.uint8))
             tr["order"].append(order.astype(np.uint8))
-            img = np.stack([o[nm]["image"] for nm in names])
+            img = np.stack([x["image"] for x in o])
             assert img.min() >= 0 and img.max() < 256 and img.shape == (a, v, v, 3)
             tr["image"].append(img.astype(np.uint8))
-            tr["direction"].append(np.array([int(o[nm]["direction"]) for nm in names], np.uint8))
-            tr["reward"].append(np.array([float(r[nm]) for nm in names], np.float64))
-            tr["terminated"].append(np.array([bool(term[nm]) for nm in names]))
-            tr["truncated"].append(np.array([bool(trunc[nm]) for nm in names]))
+            tr["direction"].append(np.array([int(x["direction"]) for x in o], np.uint8))
+            tr["reward"].append(np.array([float(r[nm]) for nm in out_keys], np.float64))
+            tr["terminated"].append(np.array([bool(term[nm]) for nm in out_keys]))
+            tr["truncated"].append(np.array([bool(trunc[nm]) for nm in out_keys]))
             tr["post_grid"].append(env.grid.state.astype(np.uint8).copy())
             tr["post_agents"].append(agent_rows(env))
             fl, mt = comp_hidden(env, keys, balls)
@@ -646,10 +669,9 @@ def main():
     ):
         cls, kw = cfg[reg]
         kw = dict(kw, **kwx)
-        if "ctce" in gname:   # recorded per agent: the harness calls the DTDE code path's twin with team-keyed dicts
-            continue
-        record_competitive(gname, kw, nt, 70, zlib.crc32(gname.encode()) % 1000 + 50, edit=comp_edit,
-                           action_p=PICKY, script=comp_script, view=view)
+        # (the CTCE group holds per-TEAM rewards and flags; its name keeps it out of the per-agent replay tests)
+        record_competitive("ctce_2v2" if "ctce" in gname else gname, kw, nt, 70, zlib.crc32(gname.encode()) % 1000 + 50,
+                           edit=comp_edit, action_p=PICKY, script=comp_script, view=view, ctce="ctce" in gname)
     record_competitive("comp_1v1_plain", dict(cfg["MultiGrid-CompetativeRedBlueDoor-v3-DTDE-1v1"][1]), 6, 320, 61)
 
     if not ONLY or "layouts" in ONLY:

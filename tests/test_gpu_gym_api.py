@@ -59,3 +59,67 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw)
         assert pz.possible_agents == list(range(agents))
         assert pz.agents == ([] if env.is_done() else [i for i in range(agents) if not d["post_agents"][n, t, i, 3]])
         env.close()
+
+
+def test_competitive_env_from_seed_dtde():
+    """CompetativeRedBlueDoorEnvV3 (DTDE 1v1 as registered): name-keyed dicts, agents acting in dict order."""
+    from multigrid_amd.gym_api import CompetativeRedBlueDoorEnv, make
+
+    spec, d = load_group("comp_1v1_plain")
+    names = spec["agent_names"]
+    a = len(names)
+    for n in range(3):
+        env = make("MultiGrid-CompetativeRedBlueDoor-v3-DTDE-1v1", layout_rng=np.random.default_rng(61 * 1000 + n))
+        assert isinstance(env, CompetativeRedBlueDoorEnv) and env.agent_names == names and env.teams == {"blue": 1, "red": 1}
+        obs, infos = env.reset(seed=61 * 7919 + n)
+        assert list(obs) == names and obs[names[0]]["image"].shape == (5, 5, 3)
+        np.testing.assert_array_equal(np.stack([obs[k]["image"] for k in names]), d["reset_image"][n])
+        np.testing.assert_array_equal(env.grid_state, d["layout_grid"][n])
+        for t in range(min(150, int(d["length"][n]))):
+            acts = {names[i]: int(d["actions"][n, t, i]) for i in d["order"][n, t]}
+            o, r, term, trunc, info = env.step(acts)
+            where = f"comp_1v1_plain[{n}] step {t}"
+            np.testing.assert_array_equal(np.stack([o[k]["image"] for k in names]), d["image"][n, t], err_msg=where)
+            assert [int(o[k]["direction"]) for k in names] == list(d["direction"][n, t]), where
+            np.testing.assert_allclose([r[k] for k in names], d["reward"][n, t], atol=1e-6, rtol=0, err_msg=where)
+            assert [term[k] for k in names] == list(d["terminated"][n, t]), where
+            assert [trunc[k] for k in names] == list(d["truncated"][n, t]), where
+        env.close()
+
+
+def test_competitive_env_ctce_team_outputs():
+    """training_scheme "CTCE": actions, observations, rewards and flags per team (ctce_step)."""
+    from multigrid_amd.gym_api import make
+
+    spec, d = load_group("ctce_2v2")
+    members = spec["team_members"]
+    for n in range(len(d["length"])):
+        env = make("MultiGrid-CompetativeRedBlueDoor-v3-CTCE-2v2", agent_view_size=7, max_steps=80)
+        teams = list(env.team_members)
+        assert [env.team_members[t] for t in teams] == members
+        env.reset(seed=n)
+        env._sim.set_state(grid=d["layout_grid"][n][None], agents=d["layout_agents"][n][None])  # the harness-edited start
+        obs = env.gen_obs()
+        np.testing.assert_array_equal(np.stack([obs[t][j]["image"] for t in teams for j in range(len(members[0]))]),
+                                      d["reset_image"][n])
+        for t in range(int(d["length"][n])):
+            order = list(d["order"][n, t])
+            team_order = []
+            for k in order:
+                tm = next(tt for tt in teams if k in env.team_members[tt])
+                if tm not in team_order:
+                    team_order.append(tm)
+            acts = {tm: [int(d["actions"][n, t, k]) for k in env.team_members[tm]] for tm in team_order}
+            o, r, term, trunc, _ = env.step(acts)
+            where = f"ctce_2v2[{n}] step {t}"
+            img = np.zeros_like(d["image"][n, t])
+            for tm in teams:
+                for j, k in enumerate(env.team_members[tm]):
+                    assert o[tm][j]["agent_id"] == j
+                    img[k] = o[tm][j]["image"]
+            np.testing.assert_array_equal(img, d["image"][n, t], err_msg=where)
+            np.testing.assert_allclose([r[tm] for tm in teams], d["reward"][n, t], atol=2e-6, rtol=0, err_msg=where)
+            assert [term[tm] for tm in teams] == list(d["terminated"][n, t]), where
+            assert [trunc[tm] for tm in teams] == list(d["truncated"][n, t]), where
+        np.testing.assert_array_equal(env.grid_state, d["post_grid"][n, int(d["length"][n]) - 1])
+        env.close()

@@ -65,3 +65,51 @@ def test_c_oracle_replays_reference(name):
         if "post_flags" in d:
             np.testing.assert_array_equal(bo.flags[live], d["post_flags"][live, t], err_msg=where + " flags")
             np.testing.assert_array_equal(bo.meta[live], d["post_meta"][live, t], err_msg=where + " ball counters")
+
+
+def team_outputs(members, reward, terminated, truncated):
+    """ctce_step's reformatting (multigrid/envs/competative_red_blue_door.py:346-368): rewards summed, flags and-ed
+    over each team's agents, in agent order."""
+    r, tm, tr = [], [], []
+    for team in members:
+        total = reward[team[0]]
+        for k in team[1:]:
+            total = total + reward[k]
+        r.append(float(total))
+        tm.append(all(bool(terminated[k]) for k in team))
+        tr.append(all(bool(truncated[k]) for k in team))
+    return r, tm, tr
+
+
+def test_ctce_outputs():
+    """training_scheme "CTCE": no "some but not all terminated" reset (:375-378 belongs to dtde_step), outputs per team."""
+    from oracle.coracle import BatchOracle
+    spec, d = load_group("ctce_2v2")
+    members = spec.pop("team_members")
+    assert spec["per_agent_outputs"] is False
+    a, n = spec["num_agents"], len(d["length"])
+    bo = BatchOracle(spec, n)
+    bo.load(np.arange(n), d["layout_grid"], d["layout_agents"], d["layout_meta"])
+    envs_py = []
+    for k in range(n):
+        env = pyref.Env(make_spec(spec))
+        env.load_layout(d["layout_grid"][k], d["layout_agents"][k], d["layout_meta"][k])
+        envs_py.append(env)
+    for t in range(int(d["length"].max())):
+        img, direction, rew, term, trunc = bo.step(d["actions"][:, t], d["order"][:, t])
+        for k in range(n):
+            if d["length"][k] <= t:
+                continue
+            where = f"ctce_2v2[{k}] step {t}"
+            o, r, tm, tr, _ = envs_py[k].step({i: int(d["actions"][k, t, i]) for i in range(a)}, d["order"][k, t])
+            for got in (team_outputs(members, r, tm, tr), team_outputs(members, rew[k], term[k], trunc[k])):
+                assert got[0] == list(d["reward"][k, t]), where + " team rewards"
+                assert got[1] == list(d["terminated"][k, t]), where + " team terminations"
+                assert got[2] == list(d["truncated"][k, t]), where + " team truncations"
+            np.testing.assert_array_equal(np.stack([o[i]["image"] for i in range(a)]), d["image"][k, t], err_msg=where)
+            np.testing.assert_array_equal(img[k], d["image"][k, t], err_msg=where)
+            np.testing.assert_array_equal(envs_py[k].grid, d["post_grid"][k, t], err_msg=where + " grid")
+            np.testing.assert_array_equal(bo.grid[k], d["post_grid"][k, t], err_msg=where + " grid (C)")
+            np.testing.assert_array_equal(envs_py[k].agents, d["post_agents"][k, t], err_msg=where + " agents")
+            np.testing.assert_array_equal(bo.agents[k], d["post_agents"][k, t], err_msg=where + " agents (C)")
+            assert envs_py[k].flags == bo.flags[k] == d["post_flags"][k, t], where + " flags"
