@@ -105,6 +105,8 @@ struct LdsMap {
     int racc;   // [ET][A]   f64 rewards of this step               } CompetativeRedBlueDoor
     int pxy;    // [ET][A]   u16 positions after the post-step hook } environments only
     int log2;   // [ET][A]   u32 cells cleared by the post-step hook}
+    int tbl;    // [NE][GS+16]   act_lanes() with up to 8 agents: per grid cell, who stands on it and who faces it.
+                // The single-step kernel keeps it where the grids go later (nothing is there during the act phase).
     int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
     int grid;   // [NE][GS]      grids of the sub-tile being observed
     int img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
@@ -1062,7 +1064,90 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     bool occupied = false, clash = false, unstable = false;
     // when nobody may write a cell and nobody asks where the others stand (the usual case in open
     // rooms that allow overlap) there is nothing to compare
-    if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+    if (A <= 8 && __ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+        // Up to 8 agents per environment: instead of comparing every pair, every agent marks the cell it stands on
+        // and the cell it faces in a table with one 16-bit entry per grid cell (low byte: who stands here, high byte:
+        // who faces this cell and acts on it) and looks up its own two cells; what the partners' actions are comes
+        // from ballots.  The same conditions as in the pairwise form below, evaluated on 8-bit agent sets.
+        uint32_t *tbl = reinterpret_cast<uint32_t *>(lds + p.o.tbl + my_slot * (p.GS + 16));
+        const uint32_t px = r0.x & 0xFF, py = (r0.x >> 8) & 0xFF;
+        const bool placed = mine && px < static_cast<uint32_t>(p.W()) && py < static_cast<uint32_t>(p.H());
+        const uint32_t pc = px * p.H() + py, me = 1u << my_agent;
+        const bool acts = mine && (ev.bits & EV_ONCELL);
+        if (placed) atomicOr(tbl + (pc >> 1), me << (16 * (pc & 1)));
+        if (acts) atomicOr(tbl + (ev.ci >> 1), (me << 8) << (16 * (ev.ci & 1)));
+        wave_sync();
+        const int sh = my_slot * A;
+        const uint32_t amask = (1u << A) - 1u;
+        const uint32_t occ_bits = EV_DROP | (p.overlap() ? 0u : EV_FWD);  // actions that ask who stands in front
+        const uint32_t try_occ = EV_TRY_DROP | (p.overlap() ? 0u : EV_TRY_FWD);
+        const uint32_t m_fwd = static_cast<uint32_t>(__ballot((ev.bits & EV_FWD) != 0) >> sh) & amask;
+        const uint32_t m_wr = static_cast<uint32_t>(__ballot((ev.bits & EV_MAY_WRITE) != 0) >> sh) & amask;
+        const uint32_t m_occ = static_cast<uint32_t>(__ballot((ev.bits & occ_bits) != 0) >> sh) & amask;
+        uint32_t at_front = 0, same_front = 0, at_its_front = 0;
+        if (acts) {
+            const uint32_t ef = (tbl[ev.ci >> 1] >> (16 * (ev.ci & 1))) & 0xFFFF;
+            at_front = ef & 0xFF;               // who stands on the cell in front of me
+            same_front = (ef >> 8) & ~me;       // who else faces the cell I face
+        }
+        if (placed) at_its_front = ((tbl[pc >> 1] >> (16 * (pc & 1))) >> 8) & 0xFF;  // who faces the cell I stand on
+        occupied = at_front != 0;  // base.py:485,512: every agent counts, terminated ones included
+        unstable = acts && (same_front & m_wr) != 0;                                  // my result depends on when they act
+        clash = need_occ && (m_fwd & (at_front | same_front)) != 0;
+        clash |= (ev.bits & EV_MAY_WRITE) && same_front != 0;                        // ... or theirs on when I act
+        clash |= (ev.bits & EV_FWD) && (m_occ & (at_its_front | same_front)) != 0;
+        clash |= unstable;
+        const uint64_t unst = __ballot(unstable);
+        if (unst != 0) {  // see the comment in the pairwise form
+            const uint32_t m_un = static_cast<uint32_t>(unst >> sh) & amask;
+            const uint32_t m_tryfwd = static_cast<uint32_t>(__ballot((ev.bits & EV_TRY_FWD) != 0) >> sh) & amask;
+            const uint32_t m_tryocc = static_cast<uint32_t>(__ballot((ev.bits & try_occ) != 0) >> sh) & amask;
+            clash |= need_occ && (m_un & m_tryfwd & (at_front | same_front) & ~me) != 0;
+            clash |= (ev.bits & EV_FWD) && (m_un & m_tryocc & (at_its_front | same_front) & ~me) != 0;
+        }
+        // Environments in which nobody may write a cell: the marked agents are all walking forward into cells that
+        // others may occupy or leave (agents may not overlap), and whether each one moves only depends on who stands
+        // in front of it when its turn comes.  Those turns are taken here, one agent per environment and round in
+        // the environment's agent order, with the table's "stands here" sets as the current positions; nothing is
+        // left for the in-order replay.  (Unmarked agents are where they were at the start of the step in the table:
+        // by the marking rule none of them stands on, enters or leaves a cell that a marked agent faces.)
+        const bool simple = mine && m_wr == 0;
+        if (__ballot(clash && simple) != 0) {
+            uint8_t *ordb = lds + p.o.ord + (s0 + my_slot) * A;
+            if (p.order == nullptr && simple && my_agent == 0) {  // the environment's order of this step, see order_key()
+                const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
+                const uint32_t key = order_key(p, env0 + s0 + my_slot, h0.y, static_cast<int>(h0.x) + 1);
+                uint64_t ordw = 0x0706050403020100ull;
+                uint32_t word = 0;
+#pragma unroll 1
+                for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                    const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                    const uint64_t d = ((ordw >> (8 * k)) ^ (ordw >> (8 * j))) & 0xFF;
+                    ordw ^= (d << (8 * k)) ^ (d << (8 * j));
+                }
+#pragma unroll 1
+                for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(ordw >> (8 * k));
+            }
+            wave_sync();
+#pragma unroll 1
+            for (int n = 0; n < A; ++n) {
+                if (clash && simple && ordb[n] == my_agent) {  // base.py:464: my turn
+                    occupied = ((tbl[ev.ci >> 1] >> (16 * (ev.ci & 1))) & 0xFF) != 0;  // base.py:485, as of now
+                    if (!occupied) {  // base.py:489
+                        atomicAnd(tbl + (pc >> 1), ~(me << (16 * (pc & 1))));
+                        atomicOr(tbl + (ev.ci >> 1), me << (16 * (ev.ci & 1)));
+                    }
+                }
+                wave_sync();
+            }
+            if (simple) clash = false;
+        }
+        wave_sync();
+        // the table goes back to all-zero: the next sub-tile, or the next step, starts from a clean one
+        if (placed) reinterpret_cast<uint16_t *>(tbl)[pc] = 0;
+        if (acts) reinterpret_cast<uint16_t *>(tbl)[ev.ci] = 0;
+        wave_sync();
+    } else if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
         if (mine) pair[lane] = make_uint2((r0.x & 0xFFFFu) | (ev.fxy << 16), ev.bits);
         wave_sync();
         if (mine) {
@@ -1433,7 +1518,7 @@ template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MUL
 #define MG_WAVES_SINGLE ((SEE && !OH && !COMP && MODE == MODE_STEP) ? 4 : 1)
 #endif
 #ifndef MG_WAVES_MULTI
-#define MG_WAVES_MULTI 1
+#define MG_WAVES_MULTI 3  // the multi-step kernels need 168-182 registers; three wavefronts (168) measured best
 #endif
 __global__ __launch_bounds__(64) MG_KERNEL_ATTR
 __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))) void mg_tile_kernel(const KParams p0) {
@@ -1590,6 +1675,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             }
         }
         if (lane < ET) lsrc[lane] = -1;
+        if (MODE == MODE_STEP && !COMP && A >= PARALLEL_ACT_MIN_AGENTS && A <= 8) {
+            // act_lanes()' cell table starts all-zero (and is left so after every use)
+            uint4 *tz = reinterpret_cast<uint4 *>(lds + p.o.tbl);
+            const int nz = NE * (p.GS + 16) / 16;
+#pragma unroll 1
+            for (int i = lane; i < nz; i += 64) tz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     wave_sync();
 
@@ -1642,6 +1734,12 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (go) lds[p.o.ord + b] = go[b];
         }
         if (lane < ET) lsrc[lane] = -1;
+        if (!COMP && A >= PARALLEL_ACT_MIN_AGENTS && A <= 8) {  // the images of the last step lay over the cell table
+            uint4 *tz = reinterpret_cast<uint4 *>(lds + p.o.tbl);
+            const int nz = NE * (p.GS + 16) / 16;
+#pragma unroll 1
+            for (int i = lane; i < nz; i += 64) tz[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         wave_sync();
     }
     if (MODE == MODE_STEP) {
@@ -2618,13 +2716,17 @@ int configure(MgEnv *h, const MgConfig &c) {
             kp.o.pxy = take(2 * et * c.num_agents);
             kp.o.log2 = take(4 * et * c.num_agents);
         }
+        const bool table = c.num_agents >= PARALLEL_ACT_MIN_AGENTS && c.num_agents <= 8;  // act_lanes() cell table
         if (multi) {  // every grid of the tile stays; images are staged beside them
             kp.o.grid = take(et * (kp.GS + 16));
-            kp.o.stage = take(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np));
-            kp.o.img = kp.o.stage;  // act_lanes() scratch: idle while images are staged
+            // the staging buffer is idle during the act phase: act_lanes()' scratch or cell table lies there too
+            kp.o.stage = take(std::max(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np), table ? ne * (kp.GS + 16) : 0));
+            kp.o.img = kp.o.stage;
+            kp.o.tbl = kp.o.stage;
             return o;
         }
         kp.o.grid = take(ne * (kp.GS + 16));  // 16 bytes between grids spread them over the LDS banks
+        kp.o.tbl = kp.o.grid;
         const int grids = round_up(ne * (kp.GS + 16), 16);
         kp.o.stage = kp.o.grid;  // images are staged over the grids of the sub-tile they were made from
         kp.o.img = take(std::max(std::min(np, STAGE_LANES) * img + 32 - grids, 8 * np));  // act_lanes() scratch + overflow

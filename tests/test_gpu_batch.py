@@ -386,3 +386,33 @@ def test_crowded_rooms_at_scale(case):
             ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
     compare_state(env, ora, f"{case} final")
     env.close()
+
+
+@pytest.mark.parametrize("case", ["cfg4", "cfg5_nooverlap"])
+def test_two_shards_equal_one_batch(case):
+    """Sharding as bench.py --gpus N does it: two handles holding the halves of a batch (env_id_offset 0 and E / 2)
+    step exactly like one handle holding all of it - layout choice and the on-device agent order are functions of
+    the GLOBAL environment index - and their statistics add up."""
+    import torch
+    e, seed = 3000, 5
+    spec, pool, whole, _ = make(case, e, autoreset=1, seed=seed)
+    _, _, lo, _ = make(case, e // 2, autoreset=1, seed=seed, env_id_offset=0)
+    _, _, hi, _ = make(case, e // 2, autoreset=1, seed=seed, env_id_offset=e // 2)
+    a = spec["num_agents"]
+    outs = [x.reset() for x in (whole, lo, hi)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].image, torch.cat([outs[1].image, outs[2].image]))
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    steps0 = torch.randint(0, spec["max_steps"], (e,), generator=g, device="cuda:0", dtype=torch.int32)
+    whole.set_state(steps=steps0)
+    lo.set_state(steps=steps0[:e // 2])
+    hi.set_state(steps=steps0[e // 2:])
+    for t in range(70):
+        acts = torch.randint(0, 7, (e, a), generator=g, device="cuda:0", dtype=torch.uint8)
+        w, l, h = whole.step(acts), lo.step(acts[:e // 2].contiguous()), hi.step(acts[e // 2:].contiguous())
+        for f in ("image", "direction", "reward", "terminated", "truncated"):
+            assert torch.equal(getattr(w, f), torch.cat([getattr(l, f), getattr(h, f)])), f"{case} step {t} {f}"
+    sw, sl, sh = (x.stats().cpu().numpy() for x in (whole, lo, hi))
+    assert sw[0] > 0 and (sw[:5] == sl[:5] + sh[:5]).all() and sw[5] == sl[5] == sh[5] == 70
+    for x in (whole, lo, hi):
+        x.close()
