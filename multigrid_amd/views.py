@@ -25,6 +25,21 @@ from . import _lib
 from .batched import BatchedMultiGrid
 
 
+def competitive_v2_observation(image: torch.Tensor, direction: torch.Tensor) -> torch.Tensor:
+    """The ``(V, V, 25)`` observation of ``CompetativeRedBlueDoorWrapperV2`` (multigrid/wrappers.py:372-416) for a whole
+    batch, on the GPU: ``image`` uint8 ``[..., V, V, 3]``, ``direction`` uint8 ``[...]`` -> uint8 ``[..., V, V, 25]``.
+    Plane 0 holds the agent's direction.  The other 24 are what the wrapper's second pass of ``one_hot`` over the
+    already one-hot image leaves (:409): that pass reads the first three one-hot channels - "type is unseen", "type is
+    empty", "type is wall" - as indices into the type, colour and state groups, so planes 1 + (type == 0),
+    12 + (type == 1) and 18 + (type == 2) are set and nothing else."""
+    t = image[..., 0]
+    out = torch.zeros(image.shape[:-1] + (25,), dtype=torch.uint8, device=image.device)
+    out[..., 0] = direction[..., None, None]
+    idx = torch.stack((1 + (t == 0).long(), 12 + (t == 1).long(), 18 + (t == 2).long()), dim=-1)
+    out.scatter_(-1, idx, 1)
+    return out
+
+
 class BatchedRLlibView:
     """``MultiAgentEnv`` convention over ``sim`` (which keeps its own auto-reset mode)."""
 

@@ -284,6 +284,17 @@ def one_hot_batch(images: np.ndarray, dim_sizes: Sequence[int] = ONE_HOT_DIMS) -
     return out
 
 
+def competitive_v2_observation(image: np.ndarray, direction: int) -> np.ndarray:
+    """``CompetativeRedBlueDoorWrapperV2.observation`` for one agent (multigrid/wrappers.py:388-414), statement for
+    statement: the image is one-hot encoded in the loop over the agents (:393-402) and the result is one-hot encoded
+    AGAIN (:409; ``one_hot`` then reads the first three of its 24 channels as indices), a plane holding the direction is
+    put in front (:410-416).  ``(V, V, 3) -> (V, V, 25)``."""
+    first = one_hot(np.asarray(image).astype(np.int64))          # :402
+    second = one_hot(first.astype(np.int64))                       # :409
+    plane = np.full(second.shape[:2] + (1,), direction).astype("uint8")  # :410-412
+    return np.concatenate((plane, second), axis=2)                 # :413-416
+
+
 class Env:
     """One environment, stepped the way ``MultiGridEnv`` is (multigrid/base.py:37)."""
 

@@ -182,3 +182,17 @@ def test_streaming_stores_either_way(case, stream, monkeypatch):
         if done.any():
             break
     env.close()
+
+
+def test_competitive_v2_observation_on_device():
+    """views.competitive_v2_observation against the reference wrapper's recorded output."""
+    import os
+    import torch
+    from golden_util import GOLDEN_DIR
+    from multigrid_amd.views import competitive_v2_observation
+    with np.load(os.path.join(GOLDEN_DIR, "onehot_v2.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    for v in (7, 5):
+        got = competitive_v2_observation(torch.as_tensor(d[f"images_v{v}"], device="cuda:0"),
+                                         torch.as_tensor(d[f"directions_v{v}"], device="cuda:0"))
+        np.testing.assert_array_equal(got.cpu().numpy(), d[f"observations_v{v}"])

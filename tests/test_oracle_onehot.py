@@ -30,3 +30,15 @@ def test_through_the_wrapper():
     """What reset() / step() of the wrapped reference environment returned."""
     d = load_onehot_fixture()
     np.testing.assert_array_equal(pyref.one_hot_batch(d["wrapper_images"]), d["wrapper_onehot"])
+
+
+def test_competitive_v2_observation():
+    """The 25-plane observation of CompetativeRedBlueDoorWrapperV2, recorded from the reference
+    (tests/golden/make_golden_onehot_v2.py)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "onehot_v2.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    for v in (7, 5):
+        for im, di, want in zip(d[f"images_v{v}"], d[f"directions_v{v}"], d[f"observations_v{v}"]):
+            np.testing.assert_array_equal(pyref.competitive_v2_observation(im, int(di)), want)
