@@ -14,7 +14,7 @@ def group_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0]
                    for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     # ("ctce_2v2" holds per-TEAM rewards and flags, see tests/test_oracle_golden.py::test_ctce_outputs)
-    return [n for n in names if n not in ("layouts", "onehot", "ctce_2v2")]
+    return [n for n in names if n not in ("layouts", "onehot", "onehot_v2", "ctce_2v2")]
 
 
 def load_onehot_fixture():
