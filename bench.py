@@ -332,6 +332,7 @@ def parse_args(argv=None):
                     help="T > 1: one fused launch per T steps (mg_step_n) instead of one launch per step")
     ap.add_argument("--repeats", type=int, default=0, help="timed runs of --steps launches; the median is reported "
                     "(default: 5 when --steps < 200, else 1)")
+    ap.add_argument("--no-overlap", action="store_true", help="allow_agent_overlap=False (agents block each other)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs")
     ap.add_argument("--selftest-gloo", action="store_true",
@@ -432,7 +433,7 @@ def main(argv=None):
     repeats = args.repeats or (5 if args.steps < 200 else 1)
     T = max(1, args.fused)
     r = gpu_leg(args, args.config, num_envs, rank, world, args.steps, args.warmup, graph=args.graph, repeats=repeats,
-                steps_per_launch=T)
+                steps_per_launch=T, **({"allow_agent_overlap": False} if args.no_overlap else {}))
     spec = r["spec"]
     total_agent_steps = world * num_envs * agents * args.steps
     value = total_agent_steps / r["wall"]
@@ -450,6 +451,7 @@ def main(argv=None):
         "repeats": repeats, "ms_per_step_all_repeats": [w / args.steps * 1e3 for w in r["walls"]],
         "config": {"workload": f"{name}, {agents} agents, 7x7 view, {num_envs} envs per GPU "
                                f"({world * num_envs} total), uniform-random actions, on-device agent order, "
+                               f"{'agents may not overlap, ' if args.no_overlap else ''}"
                                f"same-step auto-reset from {args.layouts} layouts, start step counts scattered "
                                f"over [0, {r['max_steps']})",
                    "baseline_config": args.config, "envs_per_gpu": num_envs, "agents": agents,

@@ -82,7 +82,8 @@ def lib() -> ctypes.CDLL:
         L.mg_last_error.argtypes = [vp]
         L.mg_last_error.restype = ctypes.c_char_p
         L.mg_upload_layouts.argtypes = [vp, vp, vp, vp, i32]
-        L.mg_set_reward_schemes.argtypes = [vp, vp]
+        if hasattr(L, "mg_set_reward_schemes"):  # (tuning builds of older sources loaded through MGRID_LIB lack it)
+            L.mg_set_reward_schemes.argtypes = [vp, vp]
         L.mg_generate_layouts.argtypes = [vp, ctypes.POINTER(MgLayoutSpec), i32, ctypes.c_uint64]
         L.mg_reset.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
@@ -93,7 +94,7 @@ def lib() -> ctypes.CDLL:
         L.mg_set_state.argtypes = [vp] * 7
         L.mg_stats.argtypes = [vp, vp, vp]
         for name in EXPORTS:
-            if name not in ("mg_last_error",):
+            if name not in ("mg_last_error",) and hasattr(L, name):
                 getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib

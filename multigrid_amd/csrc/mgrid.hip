@@ -1043,6 +1043,10 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 // final here, whatever the order, and neither depends on nor affects what the marked agents do.
 // Runs on the NE environments from `s0`; the scratch array lives in the image staging area, which is
 // idle during the act phase.
+// CROWD: the kernel variant for 6 to 8 agents that may not overlap, where most steps have agents to compare: the
+// comparison goes through a cell-keyed table instead of over all pairs (kept out of the other variant, whose
+// code it would only lengthen).
+template <bool CROWD>
 __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int env0, int s0, int ns, int lane,
                                           int my_slot, int my_agent) {
     const int A = p.A();
@@ -1064,7 +1068,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     bool occupied = false, clash = false, unstable = false;
     // when nobody may write a cell and nobody asks where the others stand (the usual case in open
     // rooms that allow overlap) there is nothing to compare
-    if (A <= 8 && __ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+    if (CROWD && __ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
         // Up to 8 agents per environment: instead of comparing every pair, every agent marks the cell it stands on
         // and the cell it faces in a table with one 16-bit entry per grid cell (low byte: who stands here, high byte:
         // who faces this cell and acts on it) and looks up its own two cells; what the partners' actions are comes
@@ -1506,7 +1510,8 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
 // then stay in LDS from the first step to the last; per step only actions come in and observations, rewards and
 // flags go out (plus the few grid cells a step changes, which still go to HBM at once, and restarts from the pool).
 // COMP: a step of CompetativeRedBlueDoor environments (their hook runs after gen_obs and moves agents).
-template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false, bool COMP = false>
+template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false, bool COMP = false,
+          bool CROWD = false>
 #ifndef MG_KERNEL_ATTR
 #define MG_KERNEL_ATTR
 #endif
@@ -1525,6 +1530,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     extern __shared__ __align__(16) uint8_t lds[];
     static_assert(!MULTI || (MODE == MODE_STEP && !OH), "the multi-step kernel steps and writes compact images");
     static_assert(!COMP || (MODE == MODE_STEP && SMALLA && !OH && !WALLED), "CompetativeRedBlueDoor steps: one variant");
+    static_assert(!CROWD || (MODE == MODE_STEP && SMALLA && !OH && !COMP), "the cell table serves steps of up to 8 agents");
     // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
     typename std::conditional<MULTI, KParams, const KParams &>::type p = p0;
     constexpr int IMG = 3 * V * V;  // bytes per agent image
@@ -1675,7 +1681,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             }
         }
         if (lane < ET) lsrc[lane] = -1;
-        if (MODE == MODE_STEP && !COMP && A >= PARALLEL_ACT_MIN_AGENTS && A <= 8) {
+        if (CROWD) {
             // act_lanes()' cell table starts all-zero (and is left so after every use)
             uint4 *tz = reinterpret_cast<uint4 *>(lds + p.o.tbl);
             const int nz = NE * (p.GS + 16) / 16;
@@ -1734,7 +1740,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (go) lds[p.o.ord + b] = go[b];
         }
         if (lane < ET) lsrc[lane] = -1;
-        if (!COMP && A >= PARALLEL_ACT_MIN_AGENTS && A <= 8) {  // the images of the last step lay over the cell table
+        if (CROWD) {  // the images of the last step lay over the cell table
             uint4 *tz = reinterpret_cast<uint4 *>(lds + p.o.tbl);
             const int nz = NE * (p.GS + 16) / 16;
 #pragma unroll 1
@@ -1745,7 +1751,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     if (MODE == MODE_STEP) {
         if (A >= PARALLEL_ACT_MIN_AGENTS && !COMP) {
 #pragma unroll 1
-            for (int s0 = 0; s0 < net; s0 += NE) act_lanes(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
+            for (int s0 = 0; s0 < net; s0 += NE) act_lanes<CROWD>(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
         } else if (lane < net) {
             *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = ACT_REPLAY_ALL;  // every agent acts in order
         }
@@ -2484,6 +2490,7 @@ struct MgEnv {
     LdsMap o_multi{};
     size_t lds_multi = 0;  // 0: the configuration does not fit, mg_step_n falls back to one launch per step
     bool multi_enabled = true;
+    bool crowd = false;  // 6 to 8 agents that may not overlap: steps take the CROWD kernel variant
     uint8_t *hdr = nullptr, *grid = nullptr, *pool_hdr = nullptr, *pool_grid = nullptr;
     double *schemes = nullptr;  // [A][4], CompetativeRedBlueDoor only
     int64_t *stats = nullptr;
@@ -2551,6 +2558,15 @@ void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
         kp.o.oh = static_cast<int>(h->lds_bytes);  // the exchange buffer follows everything else
     }
     const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
+    if constexpr (MODE == MODE_STEP && !OH) {
+        if (h->crowd) {
+            if (see)
+                hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH, MULTI, false, true>), grid, block, lds, s, kp);
+            else
+                hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH, MULTI, false, true>), grid, block, lds, s, kp);
+            return;
+        }
+    }
     if (see && small)
         hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH, MULTI>), grid, block, lds, s, kp);
     else if (see)
@@ -2697,6 +2713,9 @@ int configure(MgEnv *h, const MgConfig &c) {
     // Small batches get small tiles: the launch then has enough wavefronts to cover the chip and
     // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
+    h->crowd = c.kind != MG_KIND_COMPETITIVE && !c.allow_agent_overlap && c.num_agents >= PARALLEL_ACT_MIN_AGENTS &&
+               c.num_agents <= 8;
+    if (const char *ev = getenv("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
     auto lds_for = [&](int ne, int g, bool multi = false) {
         const int et = ne * g, np = ne * c.num_agents;
         int o = 0;
@@ -2716,7 +2735,7 @@ int configure(MgEnv *h, const MgConfig &c) {
             kp.o.pxy = take(2 * et * c.num_agents);
             kp.o.log2 = take(4 * et * c.num_agents);
         }
-        const bool table = c.num_agents >= PARALLEL_ACT_MIN_AGENTS && c.num_agents <= 8;  // act_lanes() cell table
+        const bool table = h->crowd;  // act_lanes() cell table
         if (multi) {  // every grid of the tile stays; images are staged beside them
             kp.o.grid = take(et * (kp.GS + 16));
             // the staging buffer is idle during the act phase: act_lanes()' scratch or cell table lies there too
