@@ -81,8 +81,12 @@ constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 #ifndef MG_STAGE_LANES
 #define MG_STAGE_LANES 32
 #endif
-// With few agents per environment the in-order replay (one lane per environment) is cheaper than the
-// lane-per-agent pass plus its bookkeeping; measured crossover on MI355X.
+// From this many agents per environment on, the act phase always starts with one lane per agent (act_lanes()).
+// Below, it does so for Empty and RedBlueDoors environments, whose agents seldom get in each other's way (their
+// steps are then finished by act_lanes() alone in nearly every wavefront: measured 7 % faster on 4096 x 2 agents of
+// RedBlueDoors-8x8); BlockedUnlockPickup and LockedHallway with 2-4 agents in small rooms leave an agent for the
+// in-order replay in most wavefronts, which then pay for both forms (measured 13 % slower), so they go straight
+// to the in-order form (one lane per environment), as single-agent environments do.
 #ifndef MG_PARALLEL_ACT_MIN_AGENTS
 #define MG_PARALLEL_ACT_MIN_AGENTS 6
 #endif
@@ -138,6 +142,7 @@ struct KParams {
     __host__ __device__ bool comp() const { return (bits >> 23) & 1; }
     __host__ __device__ bool death_match() const { return (bits >> 24) & 1; }
     __host__ __device__ bool per_agent() const { return (bits >> 25) & 1; }  // dtde_step rather than ctce_step
+    __host__ __device__ bool lanes_act() const { return (bits >> 26) & 1; }  // the act phase starts with one lane per agent
     int max_steps;
     int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
     uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
@@ -1058,11 +1063,15 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     ActEval ev;
     ev.r = r0;
     ev.fxy = ev.ci = ev.w = ev.nv = ev.bits = 0u;
+    int my_act = ACT_DONE;
+    uint32_t blue_xy = 0;
     if (mine) {
         r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
         const uint32_t w0 = reinterpret_cast<const uint16_t *>(h + p.HFC)[my_agent];
         const uint2 hm = *reinterpret_cast<const uint2 *>(h + H_FLAGS);  // flags, door positions
-        ev = eval_action(p, r0, w0, lds[p.o.act + s0 * A + lane], hm.x & 0xFF, hm.y >> 16);
+        my_act = lds[p.o.act + s0 * A + lane];
+        blue_xy = hm.y >> 16;
+        ev = eval_action(p, r0, w0, my_act, hm.x & 0xFF, blue_xy);
     }
     const bool need_occ = mine && needs_occupancy(p, ev);
     bool occupied = false, clash = false, unstable = false;
@@ -1217,29 +1226,79 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     if (mine && replay) lds[p.o.tout + s0 * A + lane] = clash ? 1 : 0;  // who is left to act
     const uint32_t word = (replay ? ACT_REPLAY : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) |
                           (resync ? ACT_RESYNC : 0u);
-    if (p.kind() == MG_KIND_EMPTY) {
-        // No environment hook: where no agent is left to act, the rest of the step
-        // (multigrid/base.py:395-402 plus the bookkeeping of act_env*()) is done here, the
-        // environment's lanes agreeing through ballots.
-        const bool done = mine && !replay;
+    // Where no agent of an environment is left to act, the rest of the step (multigrid/base.py:395-402, the
+    // environment's hook and the bookkeeping of act_env*()) is done here, the environment's lanes agreeing through
+    // ballots.  The hooks look at the state the actions left (they run after gen_obs in the reference, on the
+    // returned dicts), agents in index order and - a quirk kept - terminated agents included:
+    //   Empty                no hook;
+    //   BlockedUnlockPickup  anybody carrying the box: success for all (blockedunlockpickup.py:165-167);
+    //   LockedHallway        every door that is not locked, faces a toggling agent and has not paid yet pays once
+    //                        (locked_hallway.py:200-215); left to act_env*() when a terminated agent toggles, whose
+    //                        front cell is not tracked here;
+    //   RedBlueDoors         nothing unless somebody toggles towards the blue door (redbluedoors.py:176-185): those
+    //                        environments are left to act_env*().
+    const int kind = p.kind();
+    bool hook_here = kind == MG_KIND_EMPTY;
+    bool carrier = false;   // BlockedUnlockPickup: carries the box after the actions
+    uint32_t lh_bit = 0;    // LockedHallway: colour bit of the unlocked door I toggle towards
+    if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
+        hook_here = p.succ_any();  // the class always terminates "any" (blockedunlockpickup.py:128)
+        carrier = mine && ((clash ? r0.y : ev.r.y) & 0xFF) == T_BOX;
+    } else if (kind == MG_KIND_LOCKEDHALLWAY) {
+        const bool toggles = mine && my_act == ACT_TOGGLE;
+        hook_here = (__ballot(toggles && !(ev.bits & EV_ALIVE)) & group) == 0;
+        const uint32_t wa = (ev.bits & EV_WRITE) ? ev.nv : ev.w;  // the cell in front as the step leaves it
+        if (toggles && (ev.bits & EV_ONCELL) && (wa & 15) == T_DOOR && ((wa >> 4) & 15) != S_LOCKED)
+            lh_bit = (1u << ((wa >> 8) & 7)) & FLAG_LH_MASK;
+    } else if (kind == MG_KIND_REDBLUEDOORS) {
+        hook_here = (__ballot(mine && my_act == ACT_TOGGLE && ev.fxy == blue_xy) & group) == 0;
+    }
+    {
+        const bool done = mine && !replay && hook_here;
         const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | meta
         const int step = static_cast<int>(h0.x) + 1;           // base.py:395
+        uint32_t flags = h0.z & 0xFF;
         const uint32_t my_term = (r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u);
         const uint64_t goals = __ballot(done && (ev.bits & EV_GOAL)) & group;
-        const bool all_term = (__ballot(done && my_term != 0) & group) == group;
+        uint32_t my_tout = my_term;                                                                // base.py:400
+        uint32_t my_rewm = p.joint() ? (goals ? 1u : 0u) : ((ev.bits & EV_GOAL) ? 1u : 0u);         // base.py:558-562
+        bool hook_term = false;  // the hook terminated my agent (its own flag too, not only the returned one)
+        if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
+            if (__ballot(done && carrier) & group) {  // on_success with mode "any": everybody, base.py:547-552
+                hook_term = true;
+                my_tout = 1;
+                if (p.joint() || carrier) my_rewm = 1;
+            }
+        } else if (kind == MG_KIND_LOCKEDHALLWAY) {
+            uint32_t newbits = 0, first = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const uint64_t m = __ballot(done && lh_bit == (1u << c)) & group;
+                if (m != 0 && !(flags & (1u << c))) {
+                    newbits |= 1u << c;
+                    if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+                }
+            }
+            my_rewm += p.joint() ? static_cast<uint32_t>(__popc(newbits)) : first;  // `+=`, locked_hallway.py:207-211
+            flags |= newbits;
+            if (__popc(flags & FLAG_LH_MASK) == p.num_rooms()) my_tout = 1;  // only the returned dict, :213-215
+        }
+        const bool all_term = (__ballot(done && my_tout != 0) & group) == group;
         const bool trunc = step >= p.max_steps;  // base.py:401-402
         const bool over = trunc || all_term;
         const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
+        const int paid = __popcll(__ballot(done && (my_rewm & 1)) & group) + 2 * __popcll(__ballot(done && (my_rewm & 2)) & group) +
+                         4 * __popcll(__ballot(done && (my_rewm & 4)) & group);
         if (done) {
-            lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_term);  // base.py:400
-            if (p.joint()) lds[p.o.rewm + s0 * A + lane] = goals ? 1 : 0;   // base.py:558-559
+            lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_tout);
+            lds[p.o.rewm + s0 * A + lane] = static_cast<uint8_t>(my_rewm);
+            if (hook_term) a[R_TERM] = 1;
             // a cell changed by this step goes back to HBM unless the whole grid is about to be replaced
             if (wr && !will_reset)
                 reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
                     static_cast<uint16_t>(ev.nv);
             if (my_agent == 0) {
                 const double R = step_reward(p, step);
-                const uint32_t flags = h0.z & 0xFF;
                 *reinterpret_cast<int *>(h + H_STEP) = step;
                 h[H_FLAGS] = static_cast<uint8_t>(flags | (over ? FLAG_OVER : 0u));
                 reinterpret_cast<double *>(lds + p.o.R)[s0 + my_slot] = R;
@@ -1253,16 +1312,13 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                     atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
                     atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
                 }
-                const int paid = goals ? (p.joint() ? A : __popcll(goals)) : 0;
                 if (paid != 0)
                     atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
                               static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
             }
-        } else if (mine && my_agent == 0) {
+        } else if (mine && my_agent == 0) {  // picked up by act_env*()
             *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = word;
         }
-    } else if (mine && my_agent == 0) {  // picked up by act_env*()
-        *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = word;
     }
     wave_sync();
 }
@@ -1749,7 +1805,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         wave_sync();
     }
     if (MODE == MODE_STEP) {
-        if (A >= PARALLEL_ACT_MIN_AGENTS && !COMP) {
+        if (p.lanes_act() && !COMP) {
 #pragma unroll 1
             for (int s0 = 0; s0 < net; s0 += NE) act_lanes<CROWD>(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
         } else if (lane < net) {
@@ -2713,8 +2769,12 @@ int configure(MgEnv *h, const MgConfig &c) {
     // Small batches get small tiles: the launch then has enough wavefronts to cover the chip and
     // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
-    h->crowd = c.kind != MG_KIND_COMPETITIVE && !c.allow_agent_overlap && c.num_agents >= PARALLEL_ACT_MIN_AGENTS &&
-               c.num_agents <= 8;
+    bool lanes_act = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ||
+                     (c.num_agents >= 2 && (c.kind == MG_KIND_EMPTY || c.kind == MG_KIND_REDBLUEDOORS));
+    if (const char *ev = getenv("MGRID_LANES_ACT")) lanes_act = atoi(ev) != 0 && c.num_agents >= 2;  // tuning / test override
+    lanes_act = lanes_act && c.kind != MG_KIND_COMPETITIVE;
+    if (lanes_act) kp.bits |= 1u << 26;
+    h->crowd = lanes_act && !c.allow_agent_overlap && c.num_agents >= PARALLEL_ACT_MIN_AGENTS && c.num_agents <= 8;
     if (const char *ev = getenv("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
     auto lds_for = [&](int ne, int g, bool multi = false) {
         const int et = ne * g, np = ne * c.num_agents;
@@ -2760,7 +2820,7 @@ int configure(MgEnv *h, const MgConfig &c) {
     while (ne > 1 && (c.num_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
     while (ne > 1 && lds_for(ne, 1) > 40 * 1024) --ne;
     int g = 1;
-    const int et_target = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? (c.num_agents <= 8 ? 8 : 16) : 32;
+    const int et_target = c.num_agents >= 6 ? (c.num_agents <= 8 ? 8 : 16) : 32;
     while ((g + 1) * ne <= et_target && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
