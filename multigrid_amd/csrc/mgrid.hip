@@ -282,6 +282,25 @@ __device__ __forceinline__ double reward_times(double R, int m) {
     return v;
 }
 
+#ifdef MGRID_EXPERIMENT
+// Diagnostic build only: drain memory, read the shader clock, keep it in a buffer of its own.
+#define MG_STAMP(k)                                                                        \
+    do {                                                                                   \
+        if (p.dbg_buf && !(p.dbg & 16)) {                                                  \
+            __builtin_amdgcn_s_waitcnt(0);                                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
+            if (threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + (k)] = t_; \
+        }                                                                                  \
+    } while (0)
+// Light stamp: no drain, so the pipeline keeps running; accumulates a time difference instead.
+#define MG_TICK(var)                                                                       \
+    do {                                                                                   \
+        if (p.dbg_buf && (p.dbg & 16)) var = __builtin_amdgcn_s_memtime();                 \
+    } while (0)
+#else
+#define MG_STAMP(k) do { } while (0)
+#endif
+
 // ---- act: one lane per environment -------------------------------------------------------------
 
 // index of the cell in front of an agent row (x y dir term), or FC_NONE outside the grid
@@ -721,6 +740,10 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     const uint64_t ones = 0x0101010101010101ull >> (8 * (8 - A));  // byte k = 1 for k < A
 
     if (*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot) & ACT_FINISHED) return;
+#ifdef MGRID_EXPERIMENT
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+    MG_TICK(q0);
+#endif
     const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
     const int step = static_cast<int>(h0.x) + 1;  // base.py:395
     *reinterpret_cast<int *>(h + H_STEP) = step;
@@ -728,8 +751,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     const uint32_t was_over = flags & FLAG_OVER;
     const uint32_t red_xy = h0.w & 0xFFFF, blue_xy = h0.w >> 16;
     const bool rbd = p.kind() == MG_KIND_REDBLUEDOORS;
-    const double R = step_reward(p, step);
-    reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
+    // _reward(): CompetativeRedBlueDoor adds to it as it goes; the others only work it out (a double division) where
+    // somebody is paid, everybody else's reward being 0 * R
+    double R = COMP ? step_reward(p, step) : 0.0;
 
     // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
     const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
@@ -752,6 +776,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                 ordw ^= (d << (8 * k)) ^ (d << (8 * j));
             }
         }
+#ifdef MGRID_EXPERIMENT
+        MG_TICK(q1);
+#endif
         const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
         const uint64_t setw = everyone ? ones : load_bytes(lds + p.o.tout + slot * A, A);  // byte k: agent k acts here
         termw = 0;
@@ -791,6 +818,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
     }
     if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559: a reward paid to one is paid to all
+#ifdef MGRID_EXPERIMENT
+    MG_TICK(q2);
+#endif
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
     store_bytes(lds + p.o.oterm + slot * A, termw, A);
@@ -996,6 +1026,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     if (p.kind() == MG_KIND_LOCKEDHALLWAY && __popc(flags & FLAG_LH_MASK) == p.num_rooms())
         toutw = ones;  // locked_hallway.py:213-215: only the returned dict
 
+#ifdef MGRID_EXPERIMENT
+    MG_TICK(q3);
+#endif
     store_bytes(lds + p.o.tout + slot * A, toutw, A);
     store_bytes(lds + p.o.rewm + slot * A, rewmw, A);
     const bool all_term = toutw == ones;
@@ -1004,6 +1037,8 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     const bool over = trunc || all_term;
     if (over) flags |= FLAG_OVER;
     h[H_FLAGS] = static_cast<uint8_t>(flags);
+    if (!COMP && paid != 0) R = step_reward(p, step);
+    reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
 
     const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
     *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * slot) =
@@ -1034,6 +1069,253 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             const uint32_t e = reinterpret_cast<const uint32_t *>(lds + p.o.log2)[slot * A + j];
             gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
         }
+    }
+#ifdef MGRID_EXPERIMENT
+    MG_TICK(q4);
+    if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
+        unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 25;
+        d[0] = q1 - q0;  // header read, reward, order draw
+        d[1] = q2 - q1;  // the agents' actions
+        d[2] = q3 - q2;  // hooks
+        d[3] = q4 - q3;  // flags, statistics, cells to HBM
+    }
+#endif
+}
+
+// ---- act, one lane per environment, for exactly AC = 2 or 4 agents ---------------------------------------
+//
+// Same contract and the same results as act_env_small<false>(), written for a compile-time number of agents: the
+// environment's agent rows, front cells, actions, order and the step's cell log are read from LDS once, live in
+// registers while the agents take their turns and go back once.  With the count known the per-agent lookups are
+// selects instead of dependent LDS round trips and the hooks unroll; measured, the act phase of 2- and 4-agent
+// environments takes well under half the time of the general form.
+// v[i] for a lane-varying i, as bit selects under the masks m[k] = (i == k ? ~0 : 0).  (Written as a chain of
+// `i == k ? v[k] : r` the compiler turns the selects back into an indexed load, and the arrays into scratch memory.)
+template <int AC>
+__device__ __forceinline__ void pick_masks(uint32_t (&m)[AC], int i) {
+#pragma unroll
+    for (int k = 1; k < AC; ++k) {
+        m[k] = i == k ? ~0u : 0u;
+        asm volatile("" : "+v"(m[k]));  // opaque from here on
+    }
+}
+template <int AC>
+__device__ __forceinline__ uint32_t pick(const uint32_t (&v)[AC], const uint32_t (&m)[AC]) {
+    uint32_t r = v[0];
+#pragma unroll
+    for (int k = 1; k < AC; ++k) r = (v[k] & m[k]) | (r & ~m[k]);
+    return r;
+}
+__device__ __forceinline__ uint32_t byte32(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
+
+template <int AC>
+__device__ __forceinline__ void act_env_fixed(const KParams &p, uint8_t *lds, int slot, int env) {
+    static_assert(AC == 2 || AC == 4, "two or four agents: their bytes fill a 16- or 32-bit word");
+    constexpr uint32_t ones = AC == 4 ? 0x01010101u : 0x0101u;  // byte k = 1 for every agent k
+    const int H = p.H();
+    uint8_t *h = lds + p.o.hdr + slot * p.HS;
+    const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
+    if (fl0 & ACT_FINISHED) return;
+    auto bytes_at = [&](int off) -> uint32_t {  // the environment's AC bytes of a per-agent byte array
+        if (AC == 4) return *reinterpret_cast<const uint32_t *>(lds + off + 4 * slot);
+        return *reinterpret_cast<const uint16_t *>(lds + off + 2 * slot);
+    };
+    auto bytes_to = [&](int off, uint32_t w) {
+        if (AC == 4) *reinterpret_cast<uint32_t *>(lds + off + 4 * slot) = w;
+        else *reinterpret_cast<uint16_t *>(lds + off + 2 * slot) = static_cast<uint16_t>(w);
+    };
+    // ---- everything the step reads -------------------------------------------------------------------------
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | door positions
+    uint32_t rx[AC], ry[AC];                                // agent rows: x y dir term | ct cc cs color
+#pragma unroll
+    for (int k = 0; k < AC; k += 2) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(h + H_ROWS + 8 * k);
+        rx[k] = v.x; ry[k] = v.y; rx[k + 1] = v.z; ry[k + 1] = v.w;
+    }
+    uint32_t fc[AC + 2];  // cells in front of the agents at the start of the step, then the red and the blue door
+    {
+        const uint4 q = *reinterpret_cast<const uint4 *>(h + p.HFC);  // (HFC + 16 <= HS for 2 and for 4 agents)
+        const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < AC + 2; ++k) fc[k] = (qw[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+    }
+    const uint32_t actw = bytes_at(p.o.act);
+    uint32_t ordw = p.order ? bytes_at(p.o.ord) : 0u;
+    uint32_t logv[AC];  // cells written during this step: index | value << 16, in order
+    if (AC == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(lds + p.o.log + 16 * slot);
+        logv[0] = v.x; logv[1] = v.y; logv[AC - 2] = v.z; logv[AC - 1] = v.w;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(lds + p.o.log + 8 * slot);
+        logv[0] = v.x; logv[1] = v.y;
+    }
+    const uint32_t lanes_tout = bytes_at(p.o.tout), lanes_rewm = bytes_at(p.o.rewm), lanes_oterm = bytes_at(p.o.oterm);
+
+    const int step = static_cast<int>(h0.x) + 1;  // base.py:395
+    uint32_t flags = h0.z & 0xFF;
+    const uint32_t was_over = flags & FLAG_OVER;
+    const uint32_t red_xy = h0.w & 0xFFFF, blue_xy = h0.w >> 16;
+    int nlog = (fl0 >> 16) & 0xFF;  // left by act_lanes(): number of cells written so far
+    if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
+    uint32_t termw, rewmw;  // byte k: agent k terminated / reward multiplier
+    auto cell_as_of_now = [&](uint32_t ci, uint32_t at_start) {
+        uint32_t w = at_start;
+#pragma unroll
+        for (int j = 0; j < AC; ++j)
+            if (j < nlog && (logv[j] & 0xFFFF) == ci) w = logv[j] >> 16;
+        return w;
+    };
+
+    if (fl0 & (ACT_REPLAY | ACT_REPLAY_ALL)) {
+        // agents left to act one by one in the order of base.py:457-464 (`tout` marks them; the others have acted
+        // in act_lanes() already)
+        if (p.order == nullptr) {  // see order_key()
+            const uint32_t key = order_key(p, env, h0.y, step);
+            ordw = 0x03020100u;
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = AC - 1, f = 0; k > 0; --k, ++f) {
+                const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                const uint32_t d = byte32(ordw, k) ^ byte32(ordw, j);
+                ordw ^= (d << (8 * k)) ^ (d << (8 * j));
+            }
+        }
+        const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
+        const uint32_t setw = everyone ? ones : lanes_tout;  // byte k: agent k acts here
+        rewmw = everyone ? 0u : lanes_rewm;                   // base.py:454
+        termw = 0;
+#pragma unroll
+        for (int k = 0; k < AC; ++k) termw |= (rx[k] >> 24) << (8 * k);
+#pragma unroll 1
+        for (int n = 0; n < AC; ++n) {  // base.py:464
+            const int i = min(static_cast<int>(byte32(ordw, n)), AC - 1);
+            if (byte32(setw, i) == 0) continue;
+            uint32_t im[AC], fca[AC];
+            pick_masks<AC>(im, i);
+#pragma unroll
+            for (int k = 0; k < AC; ++k) fca[k] = fc[k];
+            const uint2 r0 = make_uint2(pick<AC>(rx, im), pick<AC>(ry, im));
+            const uint32_t w = cell_as_of_now(front_index(p, r0.x), pick<AC>(fca, im));
+            ActEval ev = eval_action(p, r0, w, static_cast<int>(byte32(actw, i)), flags, blue_xy);
+            bool occupied = false;  // base.py:485,512: every agent counts, terminated ones included
+#pragma unroll
+            for (int k = 0; k < AC; ++k) occupied |= (rx[k] & 0xFFFFu) == ev.fxy;
+            finish_action(p, ev, r0, occupied);
+            if (ev.bits & EV_TERM) termw |= 1u << (8 * i);
+            if (ev.bits & EV_GOAL) rewmw = p.joint() ? ones : ((rewmw & ~(0xFFu << (8 * i))) | (1u << (8 * i)));  // base.py:558-562
+            if ((ev.bits & EV_FLIP) && (ev.bits & EV_BLUE)) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+            const bool alive = (ev.bits & EV_ALIVE) != 0, wr = (ev.bits & EV_WRITE) != 0;
+#pragma unroll
+            for (int k = 0; k < AC; ++k) {
+                if (alive && i == k) { rx[k] = ev.r.x; ry[k] = ev.r.y; }
+                if (wr && nlog == k) logv[k] = ev.ci | (ev.nv << 16);
+            }
+            if (wr) ++nlog;
+        }
+    } else {
+        // independent actions: act_lanes() has applied them already
+        termw = lanes_oterm;
+        rewmw = lanes_rewm;
+    }
+    if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559: a reward paid to one is paid to all
+
+    // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
+    uint32_t toutw = termw;
+    const bool trunc = step >= p.max_steps;
+
+    // subclass hooks run on the returned dicts, agents in index order.  An agent whose action was "toggle" has
+    // neither moved nor turned, so its front cell of the start of the step is still the cell in front of it.
+    bool term_all = false;   // a hook terminated every agent
+    uint32_t term_some = 0;  // a hook terminated these agents (mode "all")
+    const int kind = p.kind();
+    if (kind == MG_KIND_REDBLUEDOORS) {  // redbluedoors.py:176-185
+        const uint32_t cb = (blue_xy & 0xFF) * H + (blue_xy >> 8), cr = (red_xy & 0xFF) * H + (red_xy >> 8);
+        const uint32_t wb = cell_as_of_now(cb, fc[AC + 1]), wr = cell_as_of_now(cr, fc[AC]);
+#pragma unroll
+        for (int i = 0; i < AC; ++i) {
+            if (byte32(actw, i) != ACT_TOGGLE || front_xy(rx[i]) != blue_xy || (wb & 15) != T_DOOR) continue;
+            const int so = (flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
+            if (so != S_OPEN) continue;
+            if (((wr >> 4) & 15) == S_OPEN) {  // on_success, base.py:535-562
+                if (p.succ_any()) term_all = true; else term_some |= 1u << (8 * i);
+                rewmw = p.joint() ? ones : ((rewmw & ~(0xFFu << (8 * i))) | (1u << (8 * i)));
+            } else {  // on_failure, base.py:564-585
+                if (p.fail_any()) term_all = true; else term_some |= 1u << (8 * i);
+                flags |= FLAG_STALE;
+            }
+        }
+    } else if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
+        uint32_t boxw = 0;  // byte k: agent k carries the box
+#pragma unroll
+        for (int i = 0; i < AC; ++i)
+            if ((ry[i] & 0xFF) == T_BOX) boxw |= 1u << (8 * i);
+        if (boxw) {
+            // this environment always terminates "any" (blockedunlockpickup.py:128); the other branch is not
+            // reachable through the registry and keeps base.py:553-556 exact
+            if (p.succ_any()) term_all = true; else term_some |= boxw;
+            rewmw = p.joint() ? ones : ((rewmw & ~(boxw * 0xFFu)) | boxw);
+        }
+    } else if (kind == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
+#pragma unroll
+        for (int i = 0; i < AC; ++i) {
+            if (byte32(actw, i) != ACT_TOGGLE) continue;
+            const uint32_t ci = front_index(p, rx[i]);
+            if (ci == FC_NONE) continue;
+            const uint32_t w = cell_as_of_now(ci, fc[i]);
+            if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
+            const uint32_t bit = 1u << ((w >> 8) & 7);
+            if (flags & bit & FLAG_LH_MASK) continue;
+            flags |= bit & FLAG_LH_MASK;
+            rewmw += p.joint() ? ones : (1u << (8 * i));
+        }
+    }
+    if (term_all) term_some = ones;
+    toutw |= term_some;  // hooks set both the agents' own flags and the returned dict
+    if (kind == MG_KIND_LOCKEDHALLWAY && __popc(flags & FLAG_LH_MASK) == p.num_rooms())
+        toutw = ones;  // locked_hallway.py:213-215: only the returned dict
+
+    const bool all_term = toutw == ones;
+    const int paid = static_cast<int>(__builtin_amdgcn_sad_u8(rewmw, 0u, 0u));  // sum of the bytes
+    const bool over = trunc || all_term;
+    if (over) flags |= FLAG_OVER;
+    const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
+    // _reward() is only worked out (a double division) where somebody is paid: everybody else's reward is 0 * R
+    const double R = rewmw ? step_reward(p, step) : 0.0;
+
+    // ---- everything the step leaves ------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < AC; k += 2) {
+        const uint32_t t0 = byte32(term_some, k) ? 1u << 24 : 0u, t1 = byte32(term_some, k + 1) ? 1u << 24 : 0u;
+        *reinterpret_cast<uint4 *>(h + H_ROWS + 8 * k) =
+            make_uint4(t0 ? ((rx[k] & 0xFFFFFFu) | t0) : rx[k], ry[k], t1 ? ((rx[k + 1] & 0xFFFFFFu) | t1) : rx[k + 1], ry[k + 1]);
+    }
+    *reinterpret_cast<uint4 *>(h) = make_uint4(static_cast<uint32_t>(step), h0.y, (h0.z & ~0xFFu) | flags, h0.w);
+    if (AC == 4) *reinterpret_cast<uint4 *>(lds + p.o.log + 16 * slot) = make_uint4(logv[0], logv[1], logv[AC - 2], logv[AC - 1]);
+    else *reinterpret_cast<uint2 *>(lds + p.o.log + 8 * slot) = make_uint2(logv[0], logv[1]);
+    bytes_to(p.o.oterm, termw);
+    bytes_to(p.o.tout, toutw);
+    bytes_to(p.o.rewm, rewmw);
+    reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
+    *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * slot) =
+        (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
+
+    // episode statistics: touched only when something happened (rare)
+    int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
+    if (over && !was_over) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+    }
+    if (paid != 0)
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+                  static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
+
+    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
+    if (!will_reset && nlog > 0) {
+        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+#pragma unroll
+        for (int j = 0; j < AC; ++j)
+            if (j < nlog) gg[logv[j] & 0xFFFF] = static_cast<uint16_t>(logv[j] >> 16);
     }
 }
 
@@ -1298,7 +1580,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                 reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
                     static_cast<uint16_t>(ev.nv);
             if (my_agent == 0) {
-                const double R = step_reward(p, step);
+                const double R = paid != 0 ? step_reward(p, step) : 0.0;  // nobody paid: every reward is 0 * R
                 *reinterpret_cast<int *>(h + H_STEP) = step;
                 h[H_FLAGS] = static_cast<uint8_t>(flags | (over ? FLAG_OVER : 0u));
                 reinterpret_cast<double *>(lds + p.o.R)[s0 + my_slot] = R;
@@ -1537,25 +1819,6 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
     }
 }
 
-#ifdef MGRID_EXPERIMENT
-// Diagnostic build only: drain memory, read the shader clock, keep it in a buffer of its own.
-#define MG_STAMP(k)                                                                        \
-    do {                                                                                   \
-        if (p.dbg_buf && !(p.dbg & 16)) {                                                  \
-            __builtin_amdgcn_s_waitcnt(0);                                                 \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
-            if (threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + (k)] = t_; \
-        }                                                                                  \
-    } while (0)
-// Light stamp: no drain, so the pipeline keeps running; accumulates a time difference instead.
-#define MG_TICK(var)                                                                       \
-    do {                                                                                   \
-        if (p.dbg_buf && (p.dbg & 16)) var = __builtin_amdgcn_s_memtime();                 \
-    } while (0)
-#else
-#define MG_STAMP(k) do { } while (0)
-#endif
-
 // ---- the kernel ----------------------------------------------------------------------------------------
 //
 // One wavefront owns ET = G * NE consecutive environments.  Header blocks of all ET live in LDS for
@@ -1780,7 +2043,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     const int my_slot = udiv(lane, p.magic_a);  // environment (within a sub-tile) of this lane's agent
     const int my_agent = lane - my_slot * A;
 #ifdef MGRID_EXPERIMENT
-    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0;
+    unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, tc = 0;
     MG_TICK(ta0);
 #endif
     int t = 0;
@@ -1819,11 +2082,17 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         // environments that act_lanes() could not finish: hooks, or agents whose actions interact
         if (__ballot(lane < net && !(*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * lane) & ACT_FINISHED)) != 0 &&
             lane < net) {
-            if constexpr (small)
-                act_env_small<COMP>(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
-                              p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
-            else
+            if constexpr (small) {
+                if (!COMP && A == 2)
+                    act_env_fixed<2>(p, lds, lane, e0 + lane);
+                else if (!COMP && A == 4)
+                    act_env_fixed<4>(p, lds, lane, e0 + lane);
+                else
+                    act_env_small<COMP>(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
+                                        p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
+            } else {
                 act_env(p, lds, lane, e0 + lane);
+            }
         }
         wave_sync();
 #ifdef MGRID_EXPERIMENT
@@ -1872,6 +2141,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             commit(0);
         }
         wave_sync();
+#ifdef MGRID_EXPERIMENT
+        {
+            unsigned long long tb = 0;
+            MG_TICK(tb);
+            if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 29] = tb - ta2;
+        }
+#endif
         for (int s0 = 0; s0 < net; s0 += NE) {
             const int ns = min(NE, net - s0);
             const int np = ns * A;
@@ -2143,6 +2419,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     }
 
     MG_STAMP(9);
+#ifdef MGRID_EXPERIMENT
+    MG_TICK(tc);
+#endif
     if (MODE == MODE_STEP && p.autoreset() == MG_AUTORESET_NEXT_STEP) {
         uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
         if (m) {
@@ -2188,7 +2467,11 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     {
         unsigned long long tend = 0;
         MG_TICK(tend);
-        if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 23] = tend - tstart;
+        if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
+            p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 23] = tend - tstart;
+            p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 30] = tend - tc;  // restarts, header blocks back to HBM
+            p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 31] = tc - tstart;
+        }
     }
 #endif
 }

@@ -34,6 +34,8 @@ def run(cfg, agents, e, **kw):
     if int(os.environ.get("MGRID_DBG", "0")) & 16:
         n = b[:, 19].sum()
         print(f"   light ticks per wave: staging {b[:,20].mean():.0f}  act/agent lanes {b[:,21].mean():.0f}  act/env lanes {b[:,22].mean():.0f}  whole {b[:,23].mean():.0f} clk")
+        print(f"   act end -> first pass {b[:,29].mean():.0f}  start -> scalars written {b[:,31].mean():.0f}  then to the end {b[:,30].mean():.0f} clk")
+        print(f"   in-order act: setup {b[:,25].mean():.0f}  actions {b[:,26].mean():.0f}  hooks {b[:,27].mean():.0f}  tail {b[:,28].mean():.0f} clk")
         print(f"   replayed environments: {b[:,24].sum():.0f} of {e} in {(b[:,24] > 0).sum()} of {nt.value} tiles")
         print(f"   light ticks per pass: compute {b[:,16].sum()/n:.0f}  commit {b[:,17].sum()/n:.0f}  copy-out {b[:,18].sum()/n:.0f} clk ({n:.0f} passes)")
     env.close()
