@@ -694,7 +694,15 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
                   static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
     }
-    // (the cells changed by this step go back to HBM from the log, in the observation pass)
+
+    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
+    if (!will_reset) {
+        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+        for (int j = 0; j < ev.nlog; ++j) {
+            const uint32_t e = ev.log[j];
+            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+        }
+    }
 }
 
 // ---- act, up to 8 agents: the same step with per-agent bytes packed into 64-bit registers -------------
@@ -1047,7 +1055,21 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     if (COMP ? paid_sum != 0.0 : paid != 0)
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
                   static_cast<unsigned long long>(static_cast<long long>((COMP ? paid_sum : paid * R) * 16777216.0)));
-    // (the cells changed by this step go back to HBM from the logs, in the observation pass)
+
+    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
+    if (!will_reset) {
+        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+#pragma unroll 1
+        for (int j = 0; j < nlog; ++j) {
+            const uint32_t e = log[j];
+            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+        }
+#pragma unroll 1
+        for (int j = 0; j < comp_cleared; ++j) {
+            const uint32_t e = reinterpret_cast<const uint32_t *>(lds + p.o.log2)[slot * A + j];
+            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+        }
+    }
 #ifdef MGRID_EXPERIMENT
     MG_TICK(q4);
     if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
@@ -1287,7 +1309,14 @@ __device__ __forceinline__ void act_env_fixed(const KParams &p, uint8_t *lds, in
     if (paid != 0)
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
                   static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
-    // (the cells changed by this step go back to HBM from the log, in the observation pass)
+
+    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
+    if (!will_reset && nlog > 0) {
+        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+#pragma unroll
+        for (int j = 0; j < AC; ++j)
+            if (j < nlog) gg[logv[j] & 0xFFFF] = static_cast<uint16_t>(logv[j] >> 16);
+    }
 }
 
 // ---- act, one lane per agent -----------------------------------------------------------------------
@@ -1546,6 +1575,10 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
             lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_tout);
             lds[p.o.rewm + s0 * A + lane] = static_cast<uint8_t>(my_rewm);
             if (hook_term) a[R_TERM] = 1;
+            // a cell changed by this step goes back to HBM unless the whole grid is about to be replaced
+            if (wr && !will_reset)
+                reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
+                    static_cast<uint16_t>(ev.nv);
             if (my_agent == 0) {
                 const double R = paid != 0 ? step_reward(p, step) : 0.0;  // nobody paid: every reward is 0 * R
                 *reinterpret_cast<int *>(h + H_STEP) = step;
@@ -2131,20 +2164,14 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
             uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + my_slot) * (p.GS + 16));
             if (MODE == MODE_STEP) {
-                // Cells changed by this step, replayed in order (one lane per environment): into the grid in LDS and,
-                // unless the whole grid is about to be replaced by a restart, into the grid in HBM.  (The act phase
-                // leaves these stores to this point: issued there, the wait for the prefetched grids would wait for
-                // them as well - loads and stores complete in one order.)
+                // cells changed by this step, replayed in order (one lane per environment)
                 if (lane < ns && ((sub_mask >> lane) & 1)) {
                     const uint32_t *log = reinterpret_cast<const uint32_t *>(lds + p.o.log) + (s0 + lane) * A;
                     uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
-                    uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(e0 + s0 + lane) * p.GS);
                     const int n = lds[p.o.flag + 4 * (s0 + lane) + 2];
-                    const bool keep = lds[p.o.flag + 4 * (s0 + lane) + 1] == 0;
                     for (int j = 0; j < n; ++j) {
                         const uint32_t e = log[j];
                         g[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
-                        if (keep) gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
                     }
                 }
                 wave_sync();
@@ -2235,13 +2262,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 if (lane < ns && ((sub_mask >> lane) & 1)) {
                     const uint32_t *log2 = reinterpret_cast<const uint32_t *>(lds + p.o.log2) + (s0 + lane) * A;
                     uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
-                    uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(e0 + s0 + lane) * p.GS);
                     const int n2 = lds[p.o.flag + 4 * (s0 + lane) + 3];
-                    const bool keep = lds[p.o.flag + 4 * (s0 + lane) + 1] == 0;
-                    for (int j = 0; j < n2; ++j) {
-                        g[log2[j] & 0xFFFF] = static_cast<uint16_t>(log2[j] >> 16);
-                        if (keep) gg[log2[j] & 0xFFFF] = static_cast<uint16_t>(log2[j] >> 16);
-                    }
+                    for (int j = 0; j < n2; ++j) g[log2[j] & 0xFFFF] = static_cast<uint16_t>(log2[j] >> 16);
                 }
                 uint32_t row_x = my_row.x;
                 if (mine) {
@@ -2308,11 +2330,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                             if (j < 3) wdst[M] = px[M];
                         }
                         wave_sync();
-#ifdef MGRID_EXPERIMENT
-                        if (p.image && !(p.dbg & 64)) {
-#else
                         if (p.image) {
-#endif
                             constexpr int BATCH = MG_COPY_BATCH;  // LDS reads of a batch first, then its stores
 #pragma unroll
                             for (int b0 = 0; b0 < MAXIT; b0 += BATCH) {
