@@ -464,8 +464,9 @@ def main(argv=None):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from profiles/",
                      "frac_counter_bytes": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "kernel": "mg_tile_kernel" if T == 1 else "mg_rollout_kernel",
-                     "algorithmic_bytes_per_env_step": bytes_step, "launch_us": launch_s * 1e6},
+                     "kernel": "mg_tile_kernel" if T == 1 else "mg_tile_kernel (multi-step variant)",
+                     "algorithmic_bytes_per_env_step": bytes_step, "launch_us": launch_s * 1e6,
+                     "us_per_step": launch_s / T * 1e6},
         "episode_stats": {"episodes": int(r["stats"][0]), "mean_length": float(r["stats"][1]) / max(1, int(r["stats"][0])),
                           "terminated": int(r["stats"][2]), "truncated": int(r["stats"][3]),
                           "reward_sum": float(r["stats"][4]) / 2 ** 24},
@@ -484,11 +485,15 @@ def main(argv=None):
             x = gpu_leg(args, cid, e2, 0, 1, n_steps, n_warm, one_hot=one_hot, **kw)
             ls = x["gpu_s"] / (n_steps / Tx)
             b2 = algorithmic_bytes_per_env_step(x["spec"], one_hot=one_hot, steps_per_launch=Tx)
+            b1 = algorithmic_bytes_per_env_step(x["spec"], one_hot=one_hot)
             tr = measured_traffic(n2, e2) if not label else None
             extra.append({"baseline_config": cid, "workload": f"{n2}, {a2} agents, {e2} envs" + (", " + label if label else ""),
                           "value": e2 * a2 * n_steps / x["wall"], "launch_us": ls * 1e6, "steps_per_launch": Tx,
-                          "algorithmic_bytes_per_env_step": b2,
+                          "us_per_step": ls / Tx * 1e6, "algorithmic_bytes_per_env_step": b2,
                           "roofline_frac": e2 * b2 * Tx / ls / 1e9 / HBM_PEAK_GBS,
+                          # a fused launch needs fewer bytes per step (the state travels once per launch): the same
+                          # time per step priced at the bytes of one-step launches, for comparing times
+                          "roofline_frac_at_one_step_bytes": e2 * b1 * Tx / ls / 1e9 / HBM_PEAK_GBS,
                           "roofline_frac_counter_bytes": (tr / ls / 1e9 / HBM_PEAK_GBS) if tr else None,
                           "episodes": int(x["stats"][0])})
 

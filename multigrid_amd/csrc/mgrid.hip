@@ -1829,8 +1829,9 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
 // then stay in LDS from the first step to the last; per step only actions come in and observations, rewards and
 // flags go out (plus the few grid cells a step changes, which still go to HBM at once, and restarts from the pool).
 // COMP: a step of CompetativeRedBlueDoor environments (their hook runs after gen_obs and moves agents).
+// STG: agents whose images share the LDS staging buffer on their way out (16, 32 or 64; the host picks per batch).
 template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false, bool COMP = false,
-          bool CROWD = false>
+          bool CROWD = false, int STG = MG_STAGE_LANES>
 #ifndef MG_KERNEL_ATTR
 #define MG_KERNEL_ATTR
 #endif
@@ -1850,6 +1851,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     static_assert(!MULTI || (MODE == MODE_STEP && !OH), "the multi-step kernel steps and writes compact images");
     static_assert(!COMP || (MODE == MODE_STEP && SMALLA && !OH && !WALLED), "CompetativeRedBlueDoor steps: one variant");
     static_assert(!CROWD || (MODE == MODE_STEP && SMALLA && !OH && !COMP), "the cell table serves steps of up to 8 agents");
+    static_assert(STG == 16 || STG == 32 || STG == 64, "staging width: whole 16-agent blocks of a wavefront");
     // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
     typename std::conditional<MULTI, KParams, const KParams &>::type p = p0;
     constexpr int IMG = 3 * V * V;  // bytes per agent image
@@ -2289,7 +2291,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
 #endif
 
             if (s0 == 0) MG_STAMP(7);
-            // Images leave through a small LDS buffer, STAGE_LANES agents at a time: their lanes lay the
+            // Images leave through a small LDS buffer, STG agents at a time: their lanes lay the
             // byte streams down back to back, then the whole wavefront stores the block as 16-byte pieces.
             // The stream sits `shift` bytes into the buffer so that LDS and HBM agree modulo 16.
             const size_t tile_agent0 = static_cast<size_t>(e0 + s0) * A;  // first agent of the sub-tile
@@ -2297,10 +2299,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
 #ifdef MGRID_EXPERIMENT
             if (!(p.dbg & 2))
 #endif
-            if (want_img && all_active && np % STAGE_LANES == 0 &&
+            if (want_img && all_active && np % STG == 0 &&
                 (p.image == nullptr || ((reinterpret_cast<uintptr_t>(p.image) + tile_base) & 15) == 0)) {
-                // whole blocks, 16-byte aligned in HBM (STAGE_LANES * IMG is a multiple of 16)
-                constexpr int CH = STAGE_LANES * IMG / 16;  // 16-byte pieces per block
+                // whole blocks, 16-byte aligned in HBM (STG * IMG is a multiple of 16)
+                constexpr int CH = STG * IMG / 16;  // 16-byte pieces per block
                 constexpr int MAXIT = (CH + 63) / 64;
                 // An image is 4 M + 3 bytes, so four consecutive agents fill 4 M + 3 words exactly and agent j
                 // of such a quad starts j bytes before a word boundary.  Each lane shifts its stream by j bytes
@@ -2318,13 +2320,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                         __builtin_amdgcn_update_dpp(0, static_cast<int>(px_first), 0xF9, 0xF, 0xF, false));  // quad_perm [1,2,3,3]
                     px[M] = __builtin_amdgcn_alignbyte(next0 >> 8, (px[M] & 0xFFFFFFu) | (next0 << 24), j);
                 }
-                uint32_t *wdst = reinterpret_cast<uint32_t *>(lds + p.o.stage) + ((lane & (STAGE_LANES - 1)) >> 2) * IMG + (M + 1) * j;
+                uint32_t *wdst = reinterpret_cast<uint32_t *>(lds + p.o.stage) + ((lane & (STG - 1)) >> 2) * IMG + (M + 1) * j;
                 const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.stage);
                 uint4 *dst16 = reinterpret_cast<uint4 *>(p.image + tile_base) + lane;
 #pragma unroll
-                for (int r = 0; r < 64 / STAGE_LANES; ++r) {
-                    if (r * STAGE_LANES < np) {
-                        if (lane / STAGE_LANES == r) {
+                for (int r = 0; r < 64 / STG; ++r) {
+                    if (r * STG < np) {
+                        if (lane / STG == r) {
 #pragma unroll
                             for (int k = 0; k < M; ++k) wdst[k] = px[k];
                             if (j < 3) wdst[M] = px[M];
@@ -2343,16 +2345,16 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                             }
                         }
                         if (OH && p.onehot)
-                            emit_one_hot<V>(p, lds, lds + p.o.stage, STAGE_LANES * V * V,
-                                            p.onehot + (tile_agent0 + r * STAGE_LANES) * (OH_DIM * V * V), lane, true, ~0ull,
-                                            r * STAGE_LANES);
+                            emit_one_hot<V>(p, lds, lds + p.o.stage, STG * V * V,
+                                            p.onehot + (tile_agent0 + r * STG) * (OH_DIM * V * V), lane, true, ~0ull,
+                                            r * STG);
                         wave_sync();
                     }
                 }
             } else if (want_img) {
 #pragma unroll 1
-                for (int l0 = 0; l0 < np; l0 += STAGE_LANES) {
-                    const int nl = min(STAGE_LANES, np - l0);
+                for (int l0 = 0; l0 < np; l0 += STG) {
+                    const int nl = min(STG, np - l0);
                     const size_t out_base = tile_base + static_cast<size_t>(l0) * IMG;  // byte offset of the block
                     const int shift = p.image ? static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15) : 0;
                     if (mine && lane >= l0 && lane < l0 + nl) {
@@ -2826,6 +2828,9 @@ struct MgEnv {
     size_t lds_bytes = 0;
     int num_tiles = 0;
     // the multi-step kernel (mg_step_n) keeps every grid of a tile in LDS and stages images beside them
+    LdsMap o_step{};       // single-step launches with compact images: their own staging width and LDS map
+    size_t lds_step = 0;
+    int stg_step = MG_STAGE_LANES;
     LdsMap o_multi{};
     size_t lds_multi = 0;  // 0: the configuration does not fit, mg_step_n falls back to one launch per step
     bool multi_enabled = true;
@@ -2897,6 +2902,24 @@ void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
         kp.o.oh = static_cast<int>(h->lds_bytes);  // the exchange buffer follows everything else
     }
     const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
+    if constexpr (MODE == MODE_STEP && !OH && !MULTI) {
+        // plain steps of up to 8 agents: the staging width picked for this batch, with the LDS map that goes with it
+        if (small && !h->crowd && h->stg_step != MG_STAGE_LANES) {
+            const int oh = kp.o.oh;
+            kp.o = h->o_step;
+            kp.o.oh = oh;
+            lds = h->lds_step;
+#define MG_LAUNCH_STG(SEE_, STG_) \
+    hipLaunchKernelGGL((mg_tile_kernel<V, SEE_, MODE, true, WALLED, false, false, false, false, STG_>), grid, block, lds, s, kp)
+            if (h->stg_step == 16) {
+                if (see) MG_LAUNCH_STG(true, 16); else MG_LAUNCH_STG(false, 16);
+            } else {
+                if (see) MG_LAUNCH_STG(true, 64); else MG_LAUNCH_STG(false, 64);
+            }
+#undef MG_LAUNCH_STG
+            return;
+        }
+    }
     if constexpr (MODE == MODE_STEP && !OH) {
         if (h->crowd) {
             if (see)
@@ -3059,7 +3082,7 @@ int configure(MgEnv *h, const MgConfig &c) {
     if (lanes_act) kp.bits |= 1u << 26;
     h->crowd = lanes_act && !c.allow_agent_overlap && c.num_agents >= PARALLEL_ACT_MIN_AGENTS && c.num_agents <= 8;
     if (const char *ev = getenv("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
-    auto lds_for = [&](int ne, int g, bool multi = false) {
+    auto lds_for = [&](int ne, int g, bool multi = false, int stg = STAGE_LANES) {
         const int et = ne * g, np = ne * c.num_agents;
         int o = 0;
         auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
@@ -3082,7 +3105,7 @@ int configure(MgEnv *h, const MgConfig &c) {
         if (multi) {  // every grid of the tile stays; images are staged beside them
             kp.o.grid = take(et * (kp.GS + 16));
             // the staging buffer is idle during the act phase: act_lanes()' scratch or cell table lies there too
-            kp.o.stage = take(std::max(std::max(std::min(np, STAGE_LANES) * img + 32, 8 * np), table ? ne * (kp.GS + 16) : 0));
+            kp.o.stage = take(std::max(std::max(std::min(np, stg) * img + 32, 8 * np), table ? ne * (kp.GS + 16) : 0));
             kp.o.img = kp.o.stage;
             kp.o.tbl = kp.o.stage;
             return o;
@@ -3091,7 +3114,7 @@ int configure(MgEnv *h, const MgConfig &c) {
         kp.o.tbl = kp.o.grid;
         const int grids = round_up(ne * (kp.GS + 16), 16);
         kp.o.stage = kp.o.grid;  // images are staged over the grids of the sub-tile they were made from
-        kp.o.img = take(std::max(std::min(np, STAGE_LANES) * img + 32 - grids, 8 * np));  // act_lanes() scratch + overflow
+        kp.o.img = take(std::max(std::min(np, stg) * img + 32 - grids, 8 * np));  // act_lanes() scratch + overflow
         return o;
     };
     // Measured on MI355X: with the in-order act phase (one lane per environment) about 32 environments
@@ -3121,6 +3144,26 @@ int configure(MgEnv *h, const MgConfig &c) {
         h->o_multi.oh = 0;
         h->lds_multi = need <= 64 * 1024 ? static_cast<size_t>(need) : 0;
         if (const char *ev = getenv("MGRID_MULTI_STEP")) h->multi_enabled = atoi(ev) != 0;  // tuning / test override
+    }
+    {
+        // Staging width of the plain step kernel, measured on MI355X.  Launches of at most one round of wavefronts
+        // (8 per CU) run at the speed of one wavefront's dependent chain: the whole sub-tile's images leave in one go
+        // (64; 2 % faster on 65536 x 2 and x 4 agents than 32).  Many-round launches of the lane-per-agent kind are
+        // bound by how many wavefronts fit a CU and by their store bursts: small blocks (16; 2 % faster on
+        // 131072 x 8 agents than 32 and 5 % on 2^20 x 8, where 64 is 6 % slower).  The cell-table variant stays
+        // at 32 (16 measured 2 % slower there).
+        const int tiles = (c.num_envs + ne * g - 1) / (ne * g);
+        h->stg_step = h->crowd ? 32 : tiles <= 2048 ? 64 : (lanes_act && c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? 16 : 32);
+        if (const char *ev = getenv("MGRID_STAGE")) {  // tuning / test override
+            const int v = atoi(ev);
+            if (!h->crowd && (v == 16 || v == 32 || v == 64)) h->stg_step = v;
+        }
+        h->lds_step = static_cast<size_t>(lds_for(ne, g, false, h->stg_step));
+        if (h->lds_step > 64 * 1024) {  // does not fit: the default width
+            h->stg_step = MG_STAGE_LANES;
+            h->lds_step = static_cast<size_t>(lds_for(ne, g, false, h->stg_step));
+        }
+        h->o_step = kp.o;
     }
     h->lds_bytes = static_cast<size_t>(lds_for(ne, g));
 #ifdef MGRID_EXPERIMENT
