@@ -359,6 +359,41 @@ def test_explicit_tile_shapes(case, tile, monkeypatch):
     env.close()
 
 
+@pytest.mark.parametrize("stage", ["16", "32", "64"])
+@pytest.mark.parametrize("case,lanes", [("cfg3", None), ("cfg4", None), ("cfg5", None), ("cfg2", "0"), ("cfg2", "1"),
+                                        ("cfg4", "1"), ("odd3", None), ("single", None)])
+def test_staging_widths_and_act_forms(case, lanes, stage, monkeypatch):
+    """The step kernel's variants that the library otherwise picks by batch size and kind: images staged 16, 32 or 64
+    agents at a time (MGRID_STAGE), and the act phase started with one lane per agent or per environment
+    (MGRID_LANES_ACT).  Same contract as everywhere: bit-exact against the C oracle, same-step auto-reset."""
+    monkeypatch.setenv("MGRID_STAGE", stage)
+    if lanes is not None:
+        monkeypatch.setenv("MGRID_LANES_ACT", lanes)
+    e = 777
+    spec, pool, env, ora = make(case, e, autoreset=2)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(int(stage) + 3)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    out = env.reset()
+    idx = expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    np.testing.assert_array_equal(out.image.cpu().numpy(), ora.gen_obs())
+    for t in range(70):
+        actions, order = rand_inputs(rng, e, a)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        compare(out, res, f"{case} stage {stage} lanes {lanes} step {t}")
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+    compare_state(env, ora, f"{case} stage {stage} lanes {lanes} final")
+    env.close()
+
+
 @pytest.mark.parametrize("case", ["crowd16_lh", "crowd8_rbd", "crowd8_bup", "crowd12_bup", "cfg5_nooverlap", "crowd8_empty"])
 def test_crowded_rooms_at_scale(case):
     """Many environments in which agents block each other, reach for the same objects and walk through doors
