@@ -63,6 +63,8 @@ def measured_traffic(name, num_envs):
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
+        if isinstance(d, dict) and isinstance(d.get("workloads"), list):
+            d = d["workloads"]
         for rec in (d if isinstance(d, list) else [d]):
             w = rec.get("workload", "")
             if name in w and f"{num_envs} envs" in w and "overlap" not in w and "one-hot" not in w:

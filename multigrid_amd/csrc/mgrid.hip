@@ -145,6 +145,7 @@ struct KParams {
     __host__ __device__ bool lanes_act() const { return (bits >> 26) & 1; }  // the act phase starts with one lane per agent
     int max_steps;
     int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
+    int GP;  // distance between two environments' grids in LDS: GS + 16 (a tuning build may widen it)
     uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
     uint32_t env_offset;
     uint64_t seed;
@@ -1364,7 +1365,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         // and the cell it faces in a table with one 16-bit entry per grid cell (low byte: who stands here, high byte:
         // who faces this cell and acts on it) and looks up its own two cells; what the partners' actions are comes
         // from ballots.  The same conditions as in the pairwise form below, evaluated on 8-bit agent sets.
-        uint32_t *tbl = reinterpret_cast<uint32_t *>(lds + p.o.tbl + my_slot * (p.GS + 16));
+        uint32_t *tbl = reinterpret_cast<uint32_t *>(lds + p.o.tbl + my_slot * p.GP);
         const uint32_t px = r0.x & 0xFF, py = (r0.x >> 8) & 0xFF;
         const bool placed = mine && px < static_cast<uint32_t>(p.W()) && py < static_cast<uint32_t>(p.H());
         const uint32_t pc = px * p.H() + py, me = 1u << my_agent;
@@ -1889,13 +1890,14 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     // contiguous block of the state array, so the loads need no per-lane address arithmetic
     // beyond lane * 16; environments restarted in this launch are patched in from the pool
     // afterwards (fixup), which is rare enough to stay a plain loop.
+    const int gpq = (p.GP - p.GS) >> 4;  // 16-byte pieces between two grids in LDS
     uint4 gb0, gb1, gb2, gb3, gb4;
 #if MG_PREFETCH_REGS != 5
     uint4 gb5, gb6, gb7;
 #endif
 #define MG_ISSUE1(c, r) if ((c) * 64 < n16_) r = src_[min((c) * 64 + lane, n16_ - 1)];
 #define MG_COMMIT1(c, r) \
-    if ((c) * 64 < n16_ && (c) * 64 + lane < n16_) dg_[(c) * 64 + lane + udiv((c) * 64 + lane, p.magic_per)] = r;
+    if ((c) * 64 < n16_ && (c) * 64 + lane < n16_) dg_[(c) * 64 + lane + gpq * udiv((c) * 64 + lane, p.magic_per)] = r;
 // 16-byte registers per lane for the grid prefetch (1 KiB of a sub-tile's grids each; what exceeds them is
 // loaded when the sub-tile starts).  Five cover the sub-tiles of every registered configuration up to 16 x 16
 // cells x 8 agents and keep the kernel 19 registers smaller than eight do.
@@ -1920,7 +1922,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (n16_ > 64 * MG_PREFETCH_REGS) {  // grids beyond what the prefetch registers hold
             const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0 + s0_) * p.GS);
 #pragma unroll 1
-            for (int i = 64 * MG_PREFETCH_REGS + lane; i < n16_; i += 64) dg_[i + udiv(i, p.magic_per)] = src_[i];
+            for (int i = 64 * MG_PREFETCH_REGS + lane; i < n16_; i += 64) dg_[i + gpq * udiv(i, p.magic_per)] = src_[i];
         }
         if (MODE != MODE_OBS && __ballot(lane < ns_ && lsrc[s0_ + lane] >= 0)) {
             // environments restarted in this launch: their grid comes from the layout pool
@@ -1929,7 +1931,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 const int sub = udiv(i, p.magic_per);
                 const int src = lsrc[s0_ + sub];
                 if (src >= 0)
-                    dg_[i + sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
+                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
             }
         }
     };
@@ -1939,7 +1941,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         const uint4 *src_ = reinterpret_cast<const uint4 *>(p.grid + static_cast<size_t>(e0) * p.GS);
         uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
 #pragma unroll 1
-        for (int i = lane; i < n16_; i += 64) dg_[i + udiv(i, p.magic_per)] = src_[i];
+        for (int i = lane; i < n16_; i += 64) dg_[i + gpq * udiv(i, p.magic_per)] = src_[i];
     };
     auto patch_all_grids = [&]() {  // environments restarted since the last patch: their grid comes from the pool
         if (__ballot(lane < net && lsrc[lane] >= 0)) {
@@ -1950,7 +1952,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 const int sub = udiv(i, p.magic_per);
                 const int src = lsrc[sub];
                 if (src >= 0)
-                    dg_[i + sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
+                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
             }
         }
     };
@@ -2005,7 +2007,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (CROWD) {
             // act_lanes()' cell table starts all-zero (and is left so after every use)
             uint4 *tz = reinterpret_cast<uint4 *>(lds + p.o.tbl);
-            const int nz = NE * (p.GS + 16) / 16;
+            const int nz = NE * p.GP / 16;
 #pragma unroll 1
             for (int i = lane; i < nz; i += 64) tz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -2063,7 +2065,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (lane < ET) lsrc[lane] = -1;
         if (CROWD) {  // the images of the last step lay over the cell table
             uint4 *tz = reinterpret_cast<uint4 *>(lds + p.o.tbl);
-            const int nz = NE * (p.GS + 16) / 16;
+            const int nz = NE * p.GP / 16;
 #pragma unroll 1
             for (int i = lane; i < nz; i += 64) tz[i] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -2164,12 +2166,12 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
             const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
-            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + my_slot) * (p.GS + 16));
+            uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + my_slot) * p.GP);
             if (MODE == MODE_STEP) {
                 // cells changed by this step, replayed in order (one lane per environment)
                 if (lane < ns && ((sub_mask >> lane) & 1)) {
                     const uint32_t *log = reinterpret_cast<const uint32_t *>(lds + p.o.log) + (s0 + lane) * A;
-                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
+                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * p.GP);
                     const int n = lds[p.o.flag + 4 * (s0 + lane) + 2];
                     for (int j = 0; j < n; ++j) {
                         const uint32_t e = log[j];
@@ -2203,7 +2205,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                     if (comp_env)  // the doors of competative_red_blue_door.py:201-211 never move
                         meta = static_cast<uint32_t>(p.W() / 4) | (static_cast<uint32_t>(p.H() - 2) << 8) |
                                (static_cast<uint32_t>(p.W() / 4 + p.W() / 2 - 1) << 16) | (1u << 24);
-                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
+                    const uint16_t *g = reinterpret_cast<const uint16_t *>(lds + p.o.grid + (gslot0 + lane) * p.GP);
                     const uint32_t last = static_cast<uint32_t>(p.W() * p.H() - 1);
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A] = g[min((meta & 0xFF) * p.H() + ((meta >> 8) & 0xFF), last)];
                     reinterpret_cast<uint16_t *>(h + p.HFC)[A + 1] = g[min(((meta >> 16) & 0xFF) * p.H() + (meta >> 24), last)];
@@ -2253,7 +2255,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (!(p.dbg & 1))
 #endif
             if (want_img && mine)
-                observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + (gslot0 + my_slot) * (p.GS + 16), px);
+                observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + (gslot0 + my_slot) * p.GP, px);
             wave_sync();
             if (MULTI || comp_step) {
                 if (draw) my_grid[ci] = static_cast<uint16_t>(under);
@@ -2263,7 +2265,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 // what the hook did after gen_obs: cells cleared under eliminated agents, agents moved away
                 if (lane < ns && ((sub_mask >> lane) & 1)) {
                     const uint32_t *log2 = reinterpret_cast<const uint32_t *>(lds + p.o.log2) + (s0 + lane) * A;
-                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * (p.GS + 16));
+                    uint16_t *g = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + lane) * p.GP);
                     const int n2 = lds[p.o.flag + 4 * (s0 + lane) + 3];
                     for (int j = 0; j < n2; ++j) g[log2[j] & 0xFFFF] = static_cast<uint16_t>(log2[j] >> 16);
                 }
@@ -3067,6 +3069,15 @@ int configure(MgEnv *h, const MgConfig &c) {
     kp.HFC = 16 + 8 * round_up(c.num_agents, 2);
     kp.HS = round_up(kp.HFC + 2 * (c.num_agents + 2), 16);
     kp.GS = round_up(2 * c.width * c.height, 16);
+    // In LDS 16 bytes separate the grids of a sub-tile, which spreads most grid sizes over the banks.  Making the
+    // distance an odd number of 16-byte pieces for every size (MG_ODD_GRID_PITCH: 13 x 9 and 11 x 6 grids then get 32
+    // bytes) measured no faster on 65536 x 4 agents of LockedHallway and 2 % slower on 2-agent batches (more LDS
+    // per wavefront), so it stays a tuning switch.
+#ifdef MG_ODD_GRID_PITCH
+    kp.GP = kp.GS + (((kp.GS / 16) & 1) ? 32 : 16);
+#else
+    kp.GP = kp.GS + 16;
+#endif
     kp.env_offset = static_cast<uint32_t>(c.env_id_offset);
     kp.seed = c.seed;
 
@@ -3103,16 +3114,16 @@ int configure(MgEnv *h, const MgConfig &c) {
         }
         const bool table = h->crowd;  // act_lanes() cell table
         if (multi) {  // every grid of the tile stays; images are staged beside them
-            kp.o.grid = take(et * (kp.GS + 16));
+            kp.o.grid = take(et * kp.GP);
             // the staging buffer is idle during the act phase: act_lanes()' scratch or cell table lies there too
-            kp.o.stage = take(std::max(std::max(std::min(np, stg) * img + 32, 8 * np), table ? ne * (kp.GS + 16) : 0));
+            kp.o.stage = take(std::max(std::max(std::min(np, stg) * img + 32, 8 * np), table ? ne * kp.GP : 0));
             kp.o.img = kp.o.stage;
             kp.o.tbl = kp.o.stage;
             return o;
         }
-        kp.o.grid = take(ne * (kp.GS + 16));  // 16 bytes between grids spread them over the LDS banks
+        kp.o.grid = take(ne * kp.GP);  // 16 bytes between grids spread them over the LDS banks
         kp.o.tbl = kp.o.grid;
-        const int grids = round_up(ne * (kp.GS + 16), 16);
+        const int grids = round_up(ne * kp.GP, 16);
         kp.o.stage = kp.o.grid;  // images are staged over the grids of the sub-tile they were made from
         kp.o.img = take(std::max(std::min(np, stg) * img + 32 - grids, 8 * np));  // act_lanes() scratch + overflow
         return o;

@@ -47,7 +47,7 @@ for kt in sorted(glob.glob(os.path.join(src, "kt_*"))):
     wl = line.get("config", {}).get("workload", name)
     for r in csv.DictReader(open(os.path.join(kt, "kt_kernel_stats.csv"))):
         if STEP.search(r["Name"]):
-            stats_rows.append(dict(workload=name, kernel=r["Name"].split("(")[0].replace("void (anonymous namespace)::", ""),
+            stats_rows.append(dict(workload=name, kernel=re.sub(r"\(anonymous namespace\)::|^void |\(.*$", "", r["Name"].replace("void (anonymous namespace)::", "")),
                                    calls=r["Calls"], avg_ns=r["AverageNs"], min_ns=r["MinNs"], max_ns=r["MaxNs"],
                                    stddev=r["StdDev"], bench_launch_us=line.get("roofline", {}).get("launch_us")))
     fetch = counters(os.path.join(src, f"pmc_{name}_fetch")).get("FETCH_SIZE")

@@ -34,4 +34,9 @@ workload cfg4_65536 sq --config 4
 workload cfg4_262144 nosq --config 4 --envs 262144
 workload cfg3_65536 sq --config 3
 workload cfg2_4096 sq --config 2
+# fused launches (mg_step_n, 8 steps per launch) and the no-overlap variant: kernel-trace only
+kt cfg3_65536_T8 --config 3 --fused 8 --steps 384 --warmup 64
+kt cfg4_65536_T8 --config 4 --fused 8 --steps 384 --warmup 64
+kt cfg5_131072_T8 --config 5 --fused 8 --steps 128 --warmup 32
+kt cfg5_131072_nooverlap --config 5 --no-overlap --steps 400 --warmup 40
 echo "all passes done"
