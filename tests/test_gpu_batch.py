@@ -361,7 +361,7 @@ def test_explicit_tile_shapes(case, tile, monkeypatch):
 
 @pytest.mark.parametrize("stage", ["16", "32", "64"])
 @pytest.mark.parametrize("case,lanes", [("cfg3", None), ("cfg4", None), ("cfg5", None), ("cfg2", "0"), ("cfg2", "1"),
-                                        ("cfg4", "1"), ("odd3", None), ("single", None)])
+                                        ("cfg3", "1"), ("cfg4", "1"), ("odd3", None), ("single", None)])
 def test_staging_widths_and_act_forms(case, lanes, stage, monkeypatch):
     """The step kernel's variants that the library otherwise picks by batch size and kind: images staged 16, 32 or 64
     agents at a time (MGRID_STAGE), and the act phase started with one lane per agent or per environment
