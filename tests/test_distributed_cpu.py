@@ -78,3 +78,25 @@ def test_bench_launcher_reports_a_failed_rank():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
                        env=dict(env, MGRID_SELFTEST_FAIL_RANK="1"))
     assert p.returncode != 0 and "{" not in p.stdout
+
+
+def test_bench_finds_committed_counter_traffic():
+    """bench.py prices `roofline.traffic` from the committed PMC summaries: every BASELINE batch has a record there."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for cid, envs_ in ((2, 4096), (3, 65536), (4, 65536), (4, 262144), (5, 131072), (5, 1048576)):
+        name, agents = bench.CONFIGS[cid][0], bench.CONFIGS[cid][1]
+        tr = bench.measured_traffic(name, envs_)
+        assert tr and tr > 0, (cid, envs_)
+        alg = envs_ * bench.algorithmic_bytes_per_env_step(
+            {"num_agents": agents, "view_size": 7, **_grid_of(name)})
+        assert 0.8 < tr / alg < 1.1, (cid, envs_, tr, alg)  # cells are 2 bytes in HBM, 3 in the algorithmic count
+
+
+def _grid_of(name):
+    from multigrid_amd import envs
+    spec, _ = envs.make_spec(name, num_agents=2, agent_view_size=7)
+    return {"width": spec["width"], "height": spec["height"]}

@@ -1,0 +1,54 @@
+"""Long randomized parity run against the C oracle (test infrastructure, not a product path): many steps of mid-sized
+batches with same-step auto-reset, biased action mixes that make pickups, drops, door toggles and hook events frequent.
+    python tools/soak_parity.py [seconds per case]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import test_gpu_batch as tb
+
+CASES = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_nooverlap", "crowd8_bup", "crowd6_lh", "crowd8_rbd", "odd3", "odd5", "single"]
+MIXES = [None, [1, 1, 3, 2, 2, 3, 1], [1, 1, 2, 4, 1, 4, 0]]  # weights over left right forward pickup drop toggle done
+
+
+def run(case, seconds, e=3000, seed=0):
+    spec, pool, env, ora = tb.make(case, e, autoreset=2)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(seed)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    out = env.reset()
+    idx = tb.expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    t0, t, events = time.time(), 0, np.zeros(3, np.int64)
+    while time.time() - t0 < seconds:
+        mix = MIXES[(t // 50) % len(MIXES)]
+        if mix is None:
+            actions = rng.integers(0, 7, size=(e, a)).astype(np.uint8)
+        else:
+            w = np.asarray(mix, float) / sum(mix)
+            actions = rng.choice(7, size=(e, a), p=w).astype(np.uint8)
+        order = np.argsort(rng.random(size=(e, a)), axis=-1).astype(np.uint8)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        tb.compare(out, res, f"{case} step {t}")
+        events += [int((res[2] != 0).sum()), int(res[3].sum()), int(res[4].all(axis=1).sum())]
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = tb.expected_layout(ids, episode[ids], n_l)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+        if t % 200 == 0:
+            tb.compare_state(env, ora, f"{case} state at step {t}")
+        t += 1
+    tb.compare_state(env, ora, f"{case} final")
+    env.close()
+    print(f"{case}: {t} steps x {e} envs bit-exact; rewards paid {events[0]}, terminations {events[1]}, truncated episodes {events[2]}", flush=True)
+
+
+if __name__ == "__main__":
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+    for i, c in enumerate(CASES):
+        run(c, secs, seed=i)
+    print("soak ok")
