@@ -183,13 +183,106 @@ def face_doors_with_keys(env, rng):
                 break
 
 
+# --- a planner that plays BlockedUnlockPickup to the end -------------------------
+#
+# Agent 0 solves the task the way the mission reads, from an untouched reset(): take the ball away from the door,
+# fetch the key, unlock the door, put the key down, walk through and pick up the box (blockedunlockpickup.py:136-167).
+# Every step it looks at the live reference environment, decides the current sub-goal and takes the first action of
+# a breadth-first path to it.  The other agents only turn or idle.  Nothing of the planner is reference code: it only
+# reads the reference's objects.
+
+DIRS = ((1, 0), (0, 1), (-1, 0), (0, -1))
+
+
+def _walkable(env, x, y):
+    if not (0 <= x < env.width and 0 <= y < env.height):
+        return False
+    obj = env.grid.get(x, y)
+    return obj is None or obj.can_overlap()
+
+
+def _path_to(env, start, goals):
+    """First action of a shortest left / right / forward path from pose `start` to any pose in `goals`."""
+    from collections import deque
+    if start in goals:
+        return None
+    seen, queue = {start: None}, deque([start])
+    while queue:
+        x, y, d = cur = queue.popleft()
+        nxt = [((x, y, (d - 1) % 4), 0), ((x, y, (d + 1) % 4), 1)]
+        fx, fy = x + DIRS[d][0], y + DIRS[d][1]
+        if _walkable(env, fx, fy):
+            nxt.append(((fx, fy, d), 2))
+        for pose, act in nxt:
+            if pose in seen:
+                continue
+            seen[pose] = (cur, act)
+            if pose in goals:
+                while seen[pose][0] != start:
+                    pose = seen[pose][0]
+                return seen[pose][1]
+            queue.append(pose)
+    return 6  # unreachable: idle
+
+
+def _poses_facing(env, cell):
+    cx, cy = cell
+    return {(cx - dx, cy - dy, d) for d, (dx, dy) in enumerate(DIRS) if _walkable(env, cx - dx, cy - dy)}
+
+
+def solve_blockedunlockpickup(env, rng, t):
+    ag = env.agents[0].state
+    x, y = (int(v) for v in ag.pos)
+    pose = (x, y, int(ag.dir))
+    others = {tuple(int(v) for v in a.state.pos) for a in env.agents[1:]}
+    objs = dict(env.grid.world_objects)
+    door_pos, door = next((pos, o) for pos, o in objs.items() if isinstance(o, Door) and env.grid.get(*pos) is o)
+    blocker = (door_pos[0] - 1, door_pos[1])  # blockedunlockpickup.py: the ball lies in front of the door
+    carrying = ag.carrying
+
+    def interact(cell, action):
+        step = _path_to(env, pose, _poses_facing(env, cell))
+        return action if step is None else step
+
+    def put_down():
+        # any free cell that is not the doorway's approach and holds no agent
+        goals = set()
+        for cx in range(1, env.width - 1):
+            for cy in range(1, env.height - 1):
+                if env.grid.get(cx, cy) is None and (cx, cy) != blocker and (cx, cy) not in others and (cx, cy) != (x, y):
+                    goals |= _poses_facing(env, (cx, cy))
+        step = _path_to(env, pose, goals)
+        return 4 if step is None else step
+
+    if door.is_locked:
+        ball_there = isinstance(env.grid.get(*blocker), Ball)
+        if isinstance(carrying, Ball) or (carrying is not None and ball_there):
+            a0 = put_down()
+        elif ball_there:
+            a0 = interact(blocker, 3)
+        elif isinstance(carrying, Key):
+            a0 = interact(door_pos, 5)
+        else:
+            key_pos = next(pos for pos, o in objs.items() if isinstance(o, Key) and env.grid.get(*pos) is o)
+            a0 = interact(key_pos, 3)
+    elif not door.is_open:
+        a0 = interact(door_pos, 5)
+    elif carrying is not None and carrying is not env.obj:
+        a0 = put_down()
+    else:
+        box_pos = next((pos for pos, o in objs.items() if o is env.obj and env.grid.get(*pos) is o), None)
+        a0 = interact(box_pos, 3) if box_pos is not None else 6  # the box is in hand: the episode is over
+    rest = [int(rng.choice([0, 1, 6])) for _ in env.agents[1:]]
+    return [a0] + rest
+
+
 # --- recording ---------------------------------------------------------------
 
 ONLY = set(sys.argv[1:])  # group names to (re)generate; empty = all
 
 
 def record_group(name, build_env, n_traj, t_max, seed0, edit=None, action_p=None,
-                 extra_after_done=3, script=None):
+                 extra_after_done=3, script=None, policy=None):
     if ONLY and name not in ONLY:
         return
     rng = np.random.default_rng(seed0)
@@ -218,6 +311,8 @@ def record_group(name, build_env, n_traj, t_max, seed0, edit=None, action_p=None
         for t in range(t_max):
             if script is not None and t < len(script(n)):
                 acts = np.asarray(script(n)[t][:a], dtype=np.int64)
+            elif policy is not None:  # actions chosen by looking at the live reference environment
+                acts = np.asarray(policy(env, rng, t)[:a], dtype=np.int64)
             elif action_p is None:
                 acts = rng.integers(0, 7, size=a)
             else:
@@ -629,6 +724,11 @@ def main():
                     env.agents[1].state.dir = 0
     record_group("chaos_blockedunlockpickup", lambda: make_env(BlockedUnlockPickupEnv, 2, max_steps=90),
                  16, 80, 43, edit=bup_edit, action_p=BIASED)
+    # the task played to the end from untouched resets (2 and 3 agents, joint reward on and off)
+    record_group("solve_blockedunlockpickup", lambda: make_env(*_ck(cfg["MultiGrid-BlockedUnlockPickup-v0"], 2)),
+                 8, 120, 47, policy=solve_blockedunlockpickup)
+    record_group("solve_blockedunlockpickup3", lambda: make_env(BlockedUnlockPickupEnv, 3, joint_reward=True),
+                 4, 120, 48, policy=solve_blockedunlockpickup)
 
     def lh_edit(env, rng, n):
         if n % 2 == 0:
