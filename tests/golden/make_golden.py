@@ -276,6 +276,45 @@ def solve_blockedunlockpickup(env, rng, t):
     return [a0] + rest
 
 
+def solve_lockedhallway(env, rng, t):
+    """Agent 0 unlocks every door it can: fetch a reachable key whose door is still locked, carry it to that door,
+    toggle (locked_hallway.py:200-215 pays once per door and ends the episode when all are unlocked); keys found
+    behind the doors open the next ones.  A key without a use is put down."""
+    ag = env.agents[0].state
+    x, y = (int(v) for v in ag.pos)
+    pose = (x, y, int(ag.dir))
+    others = {tuple(int(v) for v in a.state.pos) for a in env.agents[1:]}
+    objs = {pos: o for pos, o in env.grid.world_objects.items() if env.grid.get(*pos) is o}
+    locked = {o.color: pos for pos, o in objs.items() if isinstance(o, Door) and o.is_locked}
+    rest = [int(rng.choice([0, 1, 6])) for _ in env.agents[1:]]
+
+    def towards(cell, action):  # (reachable, action to take now)
+        step = _path_to(env, pose, _poses_facing(env, cell))
+        if step is None:
+            return True, action
+        return step != 6, step
+
+    carrying = ag.carrying
+    if isinstance(carrying, Key) and carrying.color in locked:
+        ok, a0 = towards(locked[carrying.color], 5)
+        if ok:
+            return [a0] + rest
+    if carrying is not None:  # nothing to do with it (now): put it on a free cell
+        goals = set()
+        for cx in range(1, env.width - 1):
+            for cy in range(1, env.height - 1):
+                if env.grid.get(cx, cy) is None and (cx, cy) not in others and (cx, cy) != (x, y):
+                    goals |= _poses_facing(env, (cx, cy))
+        step = _path_to(env, pose, goals)
+        return [4 if step is None else step] + rest
+    for pos, o in sorted(objs.items()):
+        if isinstance(o, Key) and o.color in locked:
+            ok, a0 = towards(pos, 3)
+            if ok:
+                return [a0] + rest
+    return [6] + rest
+
+
 # --- recording ---------------------------------------------------------------
 
 ONLY = set(sys.argv[1:])  # group names to (re)generate; empty = all
@@ -729,6 +768,11 @@ def main():
                  8, 120, 47, policy=solve_blockedunlockpickup)
     record_group("solve_blockedunlockpickup3", lambda: make_env(BlockedUnlockPickupEnv, 3, joint_reward=True),
                  4, 120, 48, policy=solve_blockedunlockpickup)
+    # LockedHallway with every door unlocked in turn (rewards per door, the all-doors ending)
+    record_group("solve_lockedhallway2", lambda: make_env(*_ck(cfg["MultiGrid-LockedHallway-2Rooms-v0"], 2)),
+                 4, 200, 49, policy=solve_lockedhallway)
+    record_group("solve_lockedhallway4", lambda: make_env(*_ck(cfg["MultiGrid-LockedHallway-4Rooms-v0"], 4)),
+                 4, 400, 50, policy=solve_lockedhallway)
 
     def lh_edit(env, rng, n):
         if n % 2 == 0:
