@@ -2051,14 +2051,21 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     MG_TICK(ta0);
 #endif
     int t = 0;
+    // multi-step kernel: the next step's action and order words, loaded while this step's views are made
+    uint32_t aw_next = 0, ow_next = 0;
+    bool words_next = false;
     do {  // one pass unless MULTI
     if (MULTI && t > 0) {
         // the next step's actions and order (p.actions / p.order have moved on to its slice)
         wave_sync();
         const uint8_t *ga = p.actions + static_cast<size_t>(e0) * A;
         const uint8_t *go = p.order ? p.order + static_cast<size_t>(e0) * A : nullptr;
+        if (words_next && 4 * lane + 4 <= nag) {
+            *reinterpret_cast<uint32_t *>(lds + p.o.act + 4 * lane) = aw_next;
+            if (go) *reinterpret_cast<uint32_t *>(lds + p.o.ord + 4 * lane) = ow_next;
+        }
 #pragma unroll 1
-        for (int b = lane; b < nag; b += 64) {
+        for (int b = words_next ? min(nag & ~3, 256) + lane : lane; b < nag; b += 64) {  // what the words left over
             lds[p.o.act + b] = ga[b];
             if (go) lds[p.o.ord + b] = go[b];
         }
@@ -2110,6 +2117,17 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         }
 #endif
         MG_STAMP(2);
+        if (MULTI && t + 1 < p.T) {
+            // the act phase has consumed this step's actions: the next step's set out now and arrive during the views
+            const size_t ea = static_cast<size_t>(p.E) * A;
+            const uint8_t *ga = p.actions + ea + static_cast<size_t>(e0) * A;
+            const uint8_t *go = p.order ? p.order + ea + static_cast<size_t>(e0) * A : nullptr;
+            words_next = ((reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(go)) & 3) == 0;
+            if (words_next && 4 * lane + 4 <= nag) {
+                aw_next = *reinterpret_cast<const uint32_t *>(ga + 4 * lane);
+                if (go) ow_next = *reinterpret_cast<const uint32_t *>(go + 4 * lane);
+            }
+        }
         if (p.autoreset() == MG_AUTORESET_SAME_STEP) {
             uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
             if (m) {
