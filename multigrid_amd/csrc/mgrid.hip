@@ -96,27 +96,29 @@ constexpr int PARALLEL_ACT_MIN_AGENTS = MG_PARALLEL_ACT_MIN_AGENTS;
 #endif
 constexpr int STAGE_LANES = MG_STAGE_LANES;  // agents whose images share the LDS staging buffer; a multiple of 16
 
+// Byte offsets into the workgroup's LDS (at most 64 KiB, so 16 bits each: the whole map travels in nine scalar
+// registers instead of eighteen).
 struct LdsMap {
-    int hdr;    // [ET][HS]      header blocks of the wave's environments
-    int log;    // [ET][A]   u32 cells written by this step, in order: cell index | packed cell << 16
-    int act;    // [ET][A]   u8  actions
-    int ord;    // [ET][A]   u8  order in which agents act
-    int rewm;   // [ET][A]   u8  reward of agent k = rewm * R
-    int tout;   // [ET][A]   u8  terminated as returned to the caller
-    int oterm;  // [ET][A]   u8  terminated as seen by gen_obs
-    int flag;   // [ET][4]   u8  truncated, will-reset, number of log entries, unused
-    int R;      // [ET]      f64 _reward() of this step
-    int racc;   // [ET][A]   f64 rewards of this step               } CompetativeRedBlueDoor
-    int pxy;    // [ET][A]   u16 positions after the post-step hook } environments only
-    int log2;   // [ET][A]   u32 cells cleared by the post-step hook}
-    int tbl;    // [NE][GS+16]   act_lanes() with up to 8 agents: per grid cell, who stands on it and who faces it.
+    uint16_t hdr;    // [ET][HS]      header blocks of the wave's environments
+    uint16_t log;    // [ET][A]   u32 cells written by this step, in order: cell index | packed cell << 16
+    uint16_t act;    // [ET][A]   u8  actions
+    uint16_t ord;    // [ET][A]   u8  order in which agents act
+    uint16_t rewm;   // [ET][A]   u8  reward of agent k = rewm * R
+    uint16_t tout;   // [ET][A]   u8  terminated as returned to the caller
+    uint16_t oterm;  // [ET][A]   u8  terminated as seen by gen_obs
+    uint16_t flag;   // [ET][4]   u8  truncated, will-reset, number of log entries, unused
+    uint16_t R;      // [ET]      f64 _reward() of this step
+    uint16_t racc;   // [ET][A]   f64 rewards of this step               } CompetativeRedBlueDoor
+    uint16_t pxy;    // [ET][A]   u16 positions after the post-step hook } environments only
+    uint16_t log2;   // [ET][A]   u32 cells cleared by the post-step hook}
+    uint16_t tbl;    // [NE][GS+16]   act_lanes() with up to 8 agents: per grid cell, who stands on it and who faces it.
                 // The single-step kernel keeps it where the grids go later (nothing is there during the act phase).
-    int src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
-    int grid;   // [NE][GS]      grids of the sub-tile being observed
-    int img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
-    int stage;  // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order: starts where `grid` starts
+    uint16_t src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
+    uint16_t grid;   // [NE][GS]      grids of the sub-tile being observed
+    uint16_t img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
+    uint16_t stage;  // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order: starts where `grid` starts
                 // (the grids are dead once a sub-tile has been observed) and runs on into `img`
-    int oh;     // [192] uint4   one-hot pieces changing lanes (present only in launches that write one-hot images)
+    uint16_t oh;     // [192] uint4   one-hot pieces changing lanes (present only in launches that write one-hot images)
 };
 
 struct KParams {
