@@ -56,11 +56,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -Os, measured: the step kernel is 7 % faster than at -O3 (smaller code, and 126 instead of 129 vector
     # registers, which lets a fourth wavefront onto every SIMD)
-    cmd = [hipcc, "-Os", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # The build keeps its intermediate files in a scratch directory so that the device assembly can be checked
+    # for a code pattern this compiler was seen to get wrong (see _isa_lint.py) before the library is put in place.
+    import glob
+    import shutil
+    import tempfile
+    from ._isa_lint import find_masked_copies
+    tmp = tempfile.mkdtemp(prefix="mgrid_build_")
+    try:
+        out = os.path.join(tmp, "libmgrid_hip.so")
+        cmd = [hipcc, "-Os", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-save-temps",
+               "-I", INCLUDE_DIR, SRC_PATH, "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=tmp)
+        listings = glob.glob(os.path.join(tmp, "*gfx950*.s"))
+        if not listings:
+            raise RuntimeError("the build left no device assembly to check")
+        for path in listings:
+            hits = find_masked_copies(path)
+            if hits:
+                what = "; ".join(f"{k} {label}: {ins[0]}" for k, label, ins in hits[:3])
+                raise RuntimeError(f"device code writes vector registers before a divergent region's lanes are "
+                                   f"switched back on ({len(hits)} place(s): {what}); change the source around the "
+                                   "named kernel until the compiler stops doing that")
+        shutil.move(out, LIB_PATH)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return LIB_PATH
 
 

@@ -98,27 +98,31 @@ constexpr int STAGE_LANES = MG_STAGE_LANES;  // agents whose images share the LD
 
 // Byte offsets into the workgroup's LDS (at most 64 KiB, so 16 bits each: the whole map travels in nine scalar
 // registers instead of eighteen).
+#ifndef MG_LDS_OFFSET_TYPE
+#define MG_LDS_OFFSET_TYPE uint16_t
+#endif
+typedef MG_LDS_OFFSET_TYPE lds_off_t;
 struct LdsMap {
-    uint16_t hdr;    // [ET][HS]      header blocks of the wave's environments
-    uint16_t log;    // [ET][A]   u32 cells written by this step, in order: cell index | packed cell << 16
-    uint16_t act;    // [ET][A]   u8  actions
-    uint16_t ord;    // [ET][A]   u8  order in which agents act
-    uint16_t rewm;   // [ET][A]   u8  reward of agent k = rewm * R
-    uint16_t tout;   // [ET][A]   u8  terminated as returned to the caller
-    uint16_t oterm;  // [ET][A]   u8  terminated as seen by gen_obs
-    uint16_t flag;   // [ET][4]   u8  truncated, will-reset, number of log entries, unused
-    uint16_t R;      // [ET]      f64 _reward() of this step
-    uint16_t racc;   // [ET][A]   f64 rewards of this step               } CompetativeRedBlueDoor
-    uint16_t pxy;    // [ET][A]   u16 positions after the post-step hook } environments only
-    uint16_t log2;   // [ET][A]   u32 cells cleared by the post-step hook}
-    uint16_t tbl;    // [NE][GS+16]   act_lanes() with up to 8 agents: per grid cell, who stands on it and who faces it.
+    lds_off_t hdr;    // [ET][HS]      header blocks of the wave's environments
+    lds_off_t log;    // [ET][A]   u32 cells written by this step, in order: cell index | packed cell << 16
+    lds_off_t act;    // [ET][A]   u8  actions
+    lds_off_t ord;    // [ET][A]   u8  order in which agents act
+    lds_off_t rewm;   // [ET][A]   u8  reward of agent k = rewm * R
+    lds_off_t tout;   // [ET][A]   u8  terminated as returned to the caller
+    lds_off_t oterm;  // [ET][A]   u8  terminated as seen by gen_obs
+    lds_off_t flag;   // [ET][4]   u8  truncated, will-reset, number of log entries, unused
+    lds_off_t R;      // [ET]      f64 _reward() of this step
+    lds_off_t racc;   // [ET][A]   f64 rewards of this step               } CompetativeRedBlueDoor
+    lds_off_t pxy;    // [ET][A]   u16 positions after the post-step hook } environments only
+    lds_off_t log2;   // [ET][A]   u32 cells cleared by the post-step hook}
+    lds_off_t tbl;    // [NE][GS+16]   act_lanes() with up to 8 agents: per grid cell, who stands on it and who faces it.
                 // The single-step kernel keeps it where the grids go later (nothing is there during the act phase).
-    uint16_t src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
-    uint16_t grid;   // [NE][GS]      grids of the sub-tile being observed
-    uint16_t img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
-    uint16_t stage;  // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order: starts where `grid` starts
+    lds_off_t src;    // [ET]      i32 layout the grid is read from (-1: the environment's own grid)
+    lds_off_t grid;   // [NE][GS]      grids of the sub-tile being observed
+    lds_off_t img;    // scratch of act_lanes() (8 bytes per agent lane) and, with `grid` before it, the image staging buffer
+    lds_off_t stage;  // [STAGE_LANES][3VV]+32 image bytes on their way out, in output order: starts where `grid` starts
                 // (the grids are dead once a sub-tile has been observed) and runs on into `img`
-    uint16_t oh;     // [192] uint4   one-hot pieces changing lanes (present only in launches that write one-hot images)
+    lds_off_t oh;     // [192] uint4   one-hot pieces changing lanes (present only in launches that write one-hot images)
 };
 
 struct KParams {
@@ -1822,6 +1826,17 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
     }
 }
 
+// A kernel argument read where it is needed instead of at kernel entry: the compiler loads a by-value argument
+// struct as a whole up front and then keeps (or spills) every field for the length of the kernel.  `off` is the
+// field's offset in KParams, the kernel's only argument.
+template <typename T>
+__device__ __forceinline__ T late_arg(size_t off) {
+    typedef const __attribute__((address_space(4))) char *karg_ptr;
+    karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));  // opaque: the load below cannot move up past this point
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(base + off);
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------------
 //
 // One wavefront owns ET = G * NE consecutive environments.  Header blocks of all ET live in LDS for
@@ -2428,17 +2443,25 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     }
 
     // ---- per-agent scalars: one coalesced element per lane ---------------------------------------------
+    uint8_t *out_direction = p.direction, *out_terminated = p.terminated, *out_truncated = p.truncated;
+    float *out_reward = p.reward;
+    if constexpr (!MULTI) {  // (the multi-step kernel moves these pointers on from step to step)
+        out_direction = late_arg<uint8_t *>(offsetof(KParams, direction));
+        out_reward = late_arg<float *>(offsetof(KParams, reward));
+        out_terminated = late_arg<uint8_t *>(offsetof(KParams, terminated));
+        out_truncated = late_arg<uint8_t *>(offsetof(KParams, truncated));
+    }
     for (int s = lane; s < nag; s += 64) {
         const int slot = udiv(s, p.magic_a);
         if (!((active_mask >> slot) & 1)) continue;
         const size_t o = static_cast<size_t>(e0) * A + s;
-        if (p.direction) p.direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
+        if (out_direction) out_direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
         if (MODE == MODE_STEP) {
-            if (p.reward)
-                p.reward[o] = COMP ? static_cast<float>(reinterpret_cast<const double *>(lds + p.o.racc)[s])
-                                       : static_cast<float>(reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]));
-            if (p.terminated) p.terminated[o] = lds[p.o.tout + s];
-            if (p.truncated) p.truncated[o] = lds[p.o.flag + 4 * slot];
+            if (out_reward)
+                out_reward[o] = COMP ? static_cast<float>(reinterpret_cast<const double *>(lds + p.o.racc)[s])
+                                     : static_cast<float>(reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]));
+            if (out_terminated) out_terminated[o] = lds[p.o.tout + s];
+            if (out_truncated) out_truncated[o] = lds[p.o.flag + 4 * slot];
         }
     }
 
