@@ -50,3 +50,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_build_check_recognises_a_masked_copy(tmp_path):
+    """The scan `_lib.build` runs over the device assembly: a vector instruction between a join label and the
+    instruction that switches the lanes back on is reported, the regular order is not."""
+    from multigrid_amd._isa_lint import find_masked_copies
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zkernel_a: ; @_Zkernel_a\n\ts_cbranch_execz .LBB1_2\n\tv_add_u32_e32 v1, 1, v1\n.LBB1_2:\n"
+                   "\tv_mov_b32_e32 v67, v63\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n")
+    good = tmp_path / "good.s"
+    good.write_text("_Zkernel_b: ; @_Zkernel_b\n\ts_cbranch_execz .LBB1_2\n\tv_add_u32_e32 v1, 1, v1\n.LBB1_2:\n"
+                    "\ts_or_b64 exec, exec, s[2:3]\n\tv_mov_b32_e32 v67, v63\n\ts_endpgm\n")
+    hits = find_masked_copies(str(bad))
+    assert len(hits) == 1 and hits[0][0] == "_Zkernel_a" and hits[0][1] == ".LBB1_2"
+    assert find_masked_copies(str(good)) == []
