@@ -183,6 +183,22 @@ struct KParams {
 #endif
 };
 
+// A kernel argument read where it is needed instead of at kernel entry: the compiler loads a by-value argument
+// struct as a whole up front and then keeps (or spills) every field for the length of the kernel.  `off` is the
+// field's offset in KParams, the kernel's only argument.
+template <typename T>
+__device__ __forceinline__ T late_arg(size_t off) {
+    typedef const __attribute__((address_space(4))) char *karg_ptr;
+    karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));  // opaque: the load below cannot move up past this point
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(base + off);
+}
+
+// this workgroup's shard of the episode statistics (touched rarely: the pointer is fetched where it is needed)
+__device__ __forceinline__ int64_t *stats_shard() {
+    return late_arg<int64_t *>(offsetof(KParams, stats)) + (blockIdx.x & 63) * MG_NUM_STATS;
+}
+
 constexpr uint32_t FC_NONE = 0x7FFF;  // "no cell": the position lies outside the grid
 
 __device__ __forceinline__ uint32_t pack_cell(uint32_t t, uint32_t c, uint32_t s) {
@@ -690,15 +706,14 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     fl[2] = static_cast<uint8_t>(ev.nlog);
 
     // episode statistics: touched only when something happened (rare)
-    int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
     if (over && !was_over) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
     }
     if (paid != 0) {
         const double R = reinterpret_cast<const double *>(lds + p.o.R)[slot];
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
                   static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
     }
 
@@ -1053,14 +1068,13 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         (static_cast<uint32_t>(comp_cleared) << 24);
 
     // episode statistics: touched only when something happened (rare)
-    int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
     if (over && !was_over) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
     }
     if (COMP ? paid_sum != 0.0 : paid != 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
                   static_cast<unsigned long long>(static_cast<long long>((COMP ? paid_sum : paid * R) * 16777216.0)));
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
@@ -1307,14 +1321,13 @@ __device__ __forceinline__ void act_env_fixed(const KParams &p, uint8_t *lds, in
         (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
 
     // episode statistics: touched only when something happened (rare)
-    int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
     if (over && !was_over) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
     }
     if (paid != 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
                   static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
@@ -1595,14 +1608,13 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                     (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) |
                     ACT_FINISHED;
                 // episode statistics: touched only when something happened (rare)
-                int64_t *st = p.stats + (blockIdx.x & 63) * MG_NUM_STATS;
                 if (over && !(flags & FLAG_OVER)) {
-                    atomicAdd(reinterpret_cast<unsigned long long *>(st + 0), 1ull);
-                    atomicAdd(reinterpret_cast<unsigned long long *>(st + 1), static_cast<unsigned long long>(step));
-                    atomicAdd(reinterpret_cast<unsigned long long *>(st + (all_term ? 2 : 3)), 1ull);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
+                    atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
                 }
                 if (paid != 0)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(st + 4),
+                    atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
                               static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
             }
         } else if (mine && my_agent == 0) {  // picked up by act_env*()
@@ -1617,8 +1629,9 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
 // Executed by the whole wavefront for one environment at a time.
 __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int slot, int env, int layout,
                                            uint32_t episode, int lane) {
-    const uint4 *sh = reinterpret_cast<const uint4 *>(p.pool_hdr + static_cast<size_t>(layout) * p.HS);
-    const uint4 *sg = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(layout) * p.GS);
+    // (restarts are rare: the pool's addresses are fetched here rather than kept for the whole step)
+    const uint4 *sh = reinterpret_cast<const uint4 *>(late_arg<const uint8_t *>(offsetof(KParams, pool_hdr)) + static_cast<size_t>(layout) * p.HS);
+    const uint4 *sg = reinterpret_cast<const uint4 *>(late_arg<const uint8_t *>(offsetof(KParams, pool_grid)) + static_cast<size_t>(layout) * p.GS);
     uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr + slot * p.HS);
     uint4 *gg = reinterpret_cast<uint4 *>(p.grid + static_cast<size_t>(env) * p.GS);
     for (int i = lane; i < p.HS / 16; i += 64) {
@@ -1826,17 +1839,6 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
     }
 }
 
-// A kernel argument read where it is needed instead of at kernel entry: the compiler loads a by-value argument
-// struct as a whole up front and then keeps (or spills) every field for the length of the kernel.  `off` is the
-// field's offset in KParams, the kernel's only argument.
-template <typename T>
-__device__ __forceinline__ T late_arg(size_t off) {
-    typedef const __attribute__((address_space(4))) char *karg_ptr;
-    karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(base));  // opaque: the load below cannot move up past this point
-    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(base + off);
-}
-
 // ---- the kernel ----------------------------------------------------------------------------------------
 //
 // One wavefront owns ET = G * NE consecutive environments.  Header blocks of all ET live in LDS for
@@ -1943,12 +1945,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         }
         if (MODE != MODE_OBS && __ballot(lane < ns_ && lsrc[s0_ + lane] >= 0)) {
             // environments restarted in this launch: their grid comes from the layout pool
+            const uint8_t *pool_grid_ = late_arg<const uint8_t *>(offsetof(KParams, pool_grid));
 #pragma unroll 1
             for (int i = lane; i < n16_; i += 64) {
                 const int sub = udiv(i, p.magic_per);
                 const int src = lsrc[s0_ + sub];
                 if (src >= 0)
-                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
+                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(pool_grid_ + static_cast<size_t>(src) * p.GS)[i - sub * per];
             }
         }
     };
@@ -1962,6 +1965,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     };
     auto patch_all_grids = [&]() {  // environments restarted since the last patch: their grid comes from the pool
         if (__ballot(lane < net && lsrc[lane] >= 0)) {
+            const uint8_t *pool_grid_ = late_arg<const uint8_t *>(offsetof(KParams, pool_grid));
             const int n16_ = net * per;
             uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
 #pragma unroll 1
@@ -1969,7 +1973,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 const int sub = udiv(i, p.magic_per);
                 const int src = lsrc[sub];
                 if (src >= 0)
-                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(p.pool_grid + static_cast<size_t>(src) * p.GS)[i - sub * per];
+                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(pool_grid_ + static_cast<size_t>(src) * p.GS)[i - sub * per];
             }
         }
     };
@@ -2503,7 +2507,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     } while (MULTI && ++t < p.T);  // steps of this launch
     if (MODE != MODE_OBS) {
         // header blocks back to HBM (reset mode: only the environments that were reset)
-        uint4 *dh = reinterpret_cast<uint4 *>(p.hdr + static_cast<size_t>(e0) * p.HS);
+        uint4 *dh = reinterpret_cast<uint4 *>(late_arg<uint8_t *>(offsetof(KParams, hdr)) + static_cast<size_t>(e0) * p.HS);
         const uint4 *sh = reinterpret_cast<const uint4 *>(lds + p.o.hdr);
         const int per_h = p.HS / 16;
         for (int i = lane; i < net * per_h; i += 64)
