@@ -263,9 +263,10 @@ __device__ __forceinline__ int udiv(int n, uint32_t magic) {
 }
 
 __device__ __forceinline__ int pick_layout(const KParams &p, int env, uint32_t episode) {
-    return static_cast<int>((static_cast<uint64_t>(p.env_offset) + static_cast<uint64_t>(env) +
+    // (restarts are rare: both numbers are fetched here rather than kept for the whole step)
+    return static_cast<int>((static_cast<uint64_t>(late_arg<uint32_t>(offsetof(KParams, env_offset))) + static_cast<uint64_t>(env) +
                              static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
-                            static_cast<uint64_t>(p.num_layouts));
+                            static_cast<uint64_t>(late_arg<int>(offsetof(KParams, num_layouts))));
 }
 
 // On-device agent order (used when the caller passes no order): a Fisher-Yates shuffle of
@@ -719,7 +720,7 @@ __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset) {
-        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+        uint16_t *gg = reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env) * p.GS);
         for (int j = 0; j < ev.nlog; ++j) {
             const uint32_t e = ev.log[j];
             gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
@@ -1079,7 +1080,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset) {
-        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+        uint16_t *gg = reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env) * p.GS);
 #pragma unroll 1
         for (int j = 0; j < nlog; ++j) {
             const uint32_t e = log[j];
@@ -1332,7 +1333,7 @@ __device__ __forceinline__ void act_env_fixed(const KParams &p, uint8_t *lds, in
 
     // cells changed by this step go back to HBM unless the whole grid is about to be replaced
     if (!will_reset && nlog > 0) {
-        uint16_t *gg = reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env) * p.GS);
+        uint16_t *gg = reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env) * p.GS);
 #pragma unroll
         for (int j = 0; j < AC; ++j)
             if (j < nlog) gg[logv[j] & 0xFFFF] = static_cast<uint16_t>(logv[j] >> 16);
@@ -1597,7 +1598,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
             if (hook_term) a[R_TERM] = 1;
             // a cell changed by this step goes back to HBM unless the whole grid is about to be replaced
             if (wr && !will_reset)
-                reinterpret_cast<uint16_t *>(p.grid + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
+                reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
                     static_cast<uint16_t>(ev.nv);
             if (my_agent == 0) {
                 const double R = paid != 0 ? step_reward(p, step) : 0.0;  // nobody paid: every reward is 0 * R
@@ -2177,6 +2178,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     MG_STAMP(3);
     // ---- observe: NE environments at a time -------------------------------------------------------------
     if (passes) {
+        uint8_t *out_image = p.image;
+        if constexpr (!MULTI) out_image = late_arg<uint8_t *>(offsetof(KParams, image));  // (see the per-agent scalars)
         if (MULTI) {
             patch_all_grids();
         } else {
@@ -2341,7 +2344,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (!(p.dbg & 2))
 #endif
             if (want_img && all_active && np % STG == 0 &&
-                (p.image == nullptr || ((reinterpret_cast<uintptr_t>(p.image) + tile_base) & 15) == 0)) {
+                (out_image == nullptr || ((reinterpret_cast<uintptr_t>(out_image) + tile_base) & 15) == 0)) {
                 // whole blocks, 16-byte aligned in HBM (STG * IMG is a multiple of 16)
                 constexpr int CH = STG * IMG / 16;  // 16-byte pieces per block
                 constexpr int MAXIT = (CH + 63) / 64;
@@ -2363,7 +2366,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 }
                 uint32_t *wdst = reinterpret_cast<uint32_t *>(lds + p.o.stage) + ((lane & (STG - 1)) >> 2) * IMG + (M + 1) * j;
                 const uint4 *src16 = reinterpret_cast<const uint4 *>(lds + p.o.stage);
-                uint4 *dst16 = reinterpret_cast<uint4 *>(p.image + tile_base) + lane;
+                uint4 *dst16 = reinterpret_cast<uint4 *>(out_image + tile_base) + lane;
 #pragma unroll
                 for (int r = 0; r < 64 / STG; ++r) {
                     if (r * STG < np) {
@@ -2373,7 +2376,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                             if (j < 3) wdst[M] = px[M];
                         }
                         wave_sync();
-                        if (p.image) {
+                        if (out_image) {
                             constexpr int BATCH = MG_COPY_BATCH;  // LDS reads of a batch first, then its stores
 #pragma unroll
                             for (int b0 = 0; b0 < MAXIT; b0 += BATCH) {
@@ -2397,7 +2400,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 for (int l0 = 0; l0 < np; l0 += STG) {
                     const int nl = min(STG, np - l0);
                     const size_t out_base = tile_base + static_cast<size_t>(l0) * IMG;  // byte offset of the block
-                    const int shift = p.image ? static_cast<int>((reinterpret_cast<uintptr_t>(p.image) + out_base) & 15) : 0;
+                    const int shift = out_image ? static_cast<int>((reinterpret_cast<uintptr_t>(out_image) + out_base) & 15) : 0;
                     if (mine && lane >= l0 && lane < l0 + nl) {
                         uint8_t *dst = lds + p.o.stage + shift + (lane - l0) * IMG;
 #pragma unroll
@@ -2406,9 +2409,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                         for (int k = NPX / 4 * 4; k < NPX; ++k) __builtin_memcpy(dst + 4 * k, &px[k], min(4, IMG - 4 * k));
                     }
                     wave_sync();
-                    uint8_t *gdst = p.image + out_base - shift;
+                    uint8_t *gdst = out_image + out_base - shift;
                     const int total = shift + nl * IMG;
-                    const int nchunk = p.image ? (total + 15) / 16 : 0;
+                    const int nchunk = out_image ? (total + 15) / 16 : 0;
                     if (OH && p.onehot)
                         emit_one_hot<V>(p, lds, lds + p.o.stage + shift, nl * V * V,
                                         p.onehot + (tile_agent0 + l0) * (OH_DIM * V * V), lane, false, sub_mask, l0);
