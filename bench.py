@@ -72,6 +72,27 @@ def measured_traffic(name, num_envs):
     return best
 
 
+# Rehearsal of the multi-rank path on a box with ONE GPU (MGRID_BENCH_REHEARSE=1): every rank uses GPU 0 and the
+# collectives run over gloo on host copies.  Everything else - sharding by env_id_offset, barriers, maximum over the
+# ranks, the statistics all-reduce and its check - is the code a real `--gpus N` run executes.
+REHEARSE = os.environ.get("MGRID_BENCH_REHEARSE") == "1"
+
+
+def local_device_index():
+    return 0 if REHEARSE else int(os.environ.get("LOCAL_RANK", 0))
+
+
+def all_reduce_(t, op):
+    import torch
+    if REHEARSE and t.is_cuda:
+        c = t.cpu()
+        torch.distributed.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        torch.distributed.all_reduce(t, op=op)
+    return t
+
+
 def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one_hot=False, repeats=1,
             steps_per_launch=1, **override):
     """Times `repeats` runs of `steps` step launches each (every run bracketed by a barrier and a device
@@ -83,7 +104,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
 
     name, agents, _, _, kw = CONFIGS[cfg_id]
     spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **dict(kw, **override))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", local_device_index())
     torch.cuda.set_device(dev)
     env = BatchedMultiGrid(spec, num_envs, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
                            env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
@@ -150,7 +171,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
         if world > 1:
             torch.distributed.barrier()
             t = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            all_reduce_(t, torch.distributed.ReduceOp.MAX)
             wall, gpu_s = float(t[0]), float(t[1])
         walls.append(wall)
         gpus.append(gpu_s)
@@ -159,8 +180,11 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     check = torch.tensor([1, steps, int(stats[5])], dtype=torch.int64, device=dev)
     if world > 1:  # the path's only collective: 64 + 24 bytes over RCCL, off the step path
         from multigrid_amd import distributed
-        distributed.allreduce_stats(stats)
-        torch.distributed.all_reduce(check, op=torch.distributed.ReduceOp.SUM)
+        if REHEARSE:
+            stats = distributed.allreduce_stats(stats.cpu())
+        else:
+            distributed.allreduce_stats(stats)
+        all_reduce_(check, torch.distributed.ReduceOp.SUM)
     out = dict(spec=spec, name=name, agents=agents, num_envs=num_envs, wall=walls[mid], gpu_s=gpus[mid],
                walls=walls, stats=stats.cpu().numpy(), check=check.cpu().tolist(), max_steps=spec["max_steps"])
     env.close()
@@ -177,7 +201,7 @@ def latency_one_env(args):
 
     name, agents, _, _, kw = CONFIGS[1]
     spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", local_device_index())
     env = BatchedMultiGrid(spec, 1, device=dev, autoreset=_lib.AUTORESET_SAME_STEP, seed=1)
     grids, ags, metas, _ = layouts.make_pool(gen, 4, seed0=0)
     env.upload_layouts(grids, ags, metas)
@@ -420,7 +444,7 @@ def main(argv=None):
     import torch
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.selftest_gloo:
+        if args.selftest_gloo or REHEARSE:
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
@@ -459,7 +483,7 @@ def main(argv=None):
                    "baseline_config": args.config, "envs_per_gpu": num_envs, "agents": agents,
                    "grid": [spec["width"], spec["height"]], "steps_per_launch": T,
                    "launch": "hip_graph" if args.graph else "eager", "parallelism": f"env-shard x{world}"},
-        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+        "rccl_ranks": (None if REHEARSE else torch.distributed.get_world_size()) if world > 1 else 1,
         "collective_check": {"ranks_seen": ranks_seen, "steps_sum": steps_sum, "launches_sum": launches_sum,
                              "ok": ranks_seen == world and steps_sum == world * args.steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -474,8 +498,10 @@ def main(argv=None):
                           "reward_sum": float(r["stats"][4]) / 2 ** 24},
     }
 
+    if REHEARSE:
+        line["rehearsal"] = f"{world} ranks sharing GPU 0, collectives over gloo: exercises the multi-rank code, not a scaling number"
     if rank == 0 and world == 1 and not args.no_extra:
-        rates = memory_rates(torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))))
+        rates = memory_rates(torch.device("cuda", local_device_index()))
         line["roofline"]["measured_copy_GBs"] = rates["copy"]
         line["roofline"]["measured_fill_GBs"] = rates["fill"]
         line["roofline"]["frac_of_measured_copy"] = achieved / rates["copy"]
