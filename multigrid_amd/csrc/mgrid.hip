@@ -1873,8 +1873,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     static_assert(!COMP || (MODE == MODE_STEP && SMALLA && !OH && !WALLED), "CompetativeRedBlueDoor steps: one variant");
     static_assert(!CROWD || (MODE == MODE_STEP && SMALLA && !OH && !COMP), "the cell table serves steps of up to 8 agents");
     static_assert(STG == 16 || STG == 32 || STG == 64, "staging width: whole 16-agent blocks of a wavefront");
-    // (the multi-step kernel reaches step t's slices of the inputs and outputs at t * E * A elements)
-    const KParams &p = p0;
+    // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
+    typename std::conditional<MULTI, KParams, const KParams &>::type p = p0;
     constexpr int IMG = 3 * V * V;  // bytes per agent image
     const int lane = threadIdx.x;
     const int A = p.A(), NE = p.NE(), NC = A + 2;
@@ -2078,11 +2078,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     bool words_next = false;
     do {  // one pass unless MULTI
     if (MULTI && t > 0) {
-        // this step's actions and order
+        // the next step's actions and order (p.actions / p.order have moved on to its slice)
         wave_sync();
-        const size_t step_off = static_cast<size_t>(t) * p.E * A;
-        const uint8_t *ga = p.actions + step_off + static_cast<size_t>(e0) * A;
-        const uint8_t *go = p.order ? p.order + step_off + static_cast<size_t>(e0) * A : nullptr;
+        const uint8_t *ga = p.actions + static_cast<size_t>(e0) * A;
+        const uint8_t *go = p.order ? p.order + static_cast<size_t>(e0) * A : nullptr;
         if (words_next && 4 * lane + 4 <= nag) {
             *reinterpret_cast<uint32_t *>(lds + p.o.act + 4 * lane) = aw_next;
             if (go) *reinterpret_cast<uint32_t *>(lds + p.o.ord + 4 * lane) = ow_next;
@@ -2142,7 +2141,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         MG_STAMP(2);
         if (MULTI && t + 1 < p.T) {
             // the act phase has consumed this step's actions: the next step's set out now and arrive during the views
-            const size_t ea = static_cast<size_t>(t + 1) * p.E * A;
+            const size_t ea = static_cast<size_t>(p.E) * A;
             const uint8_t *ga = p.actions + ea + static_cast<size_t>(e0) * A;
             const uint8_t *go = p.order ? p.order + ea + static_cast<size_t>(e0) * A : nullptr;
             words_next = ((reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(go)) & 3) == 0;
@@ -2179,9 +2178,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     MG_STAMP(3);
     // ---- observe: NE environments at a time -------------------------------------------------------------
     if (passes) {
-        // (fetched here rather than kept for the whole step, see the per-agent scalars)
-        uint8_t *out_image = late_arg<uint8_t *>(offsetof(KParams, image));
-        if (MULTI && out_image) out_image += static_cast<size_t>(t) * p.E * A * IMG;
+        uint8_t *out_image = p.image;
+        if constexpr (!MULTI) out_image = late_arg<uint8_t *>(offsetof(KParams, image));  // (see the per-agent scalars)
         if (MULTI) {
             patch_all_grids();
         } else {
@@ -2452,17 +2450,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     }
 
     // ---- per-agent scalars: one coalesced element per lane ---------------------------------------------
-    // the output pointers are fetched here rather than kept (or spilled) for the whole step
-    uint8_t *out_direction = late_arg<uint8_t *>(offsetof(KParams, direction));
-    float *out_reward = late_arg<float *>(offsetof(KParams, reward));
-    uint8_t *out_terminated = late_arg<uint8_t *>(offsetof(KParams, terminated));
-    uint8_t *out_truncated = late_arg<uint8_t *>(offsetof(KParams, truncated));
-    if (MULTI) {  // step t's slices
-        const size_t step_off = static_cast<size_t>(t) * p.E * A;
-        if (out_direction) out_direction += step_off;
-        if (out_reward) out_reward += step_off;
-        if (out_terminated) out_terminated += step_off;
-        if (out_truncated) out_truncated += step_off;
+    uint8_t *out_direction = p.direction, *out_terminated = p.terminated, *out_truncated = p.truncated;
+    float *out_reward = p.reward;
+    if constexpr (!MULTI) {  // (the multi-step kernel moves these pointers on from step to step)
+        out_direction = late_arg<uint8_t *>(offsetof(KParams, direction));
+        out_reward = late_arg<float *>(offsetof(KParams, reward));
+        out_terminated = late_arg<uint8_t *>(offsetof(KParams, terminated));
+        out_truncated = late_arg<uint8_t *>(offsetof(KParams, truncated));
     }
     for (int s = lane; s < nag; s += 64) {
         const int slot = udiv(s, p.magic_a);
@@ -2502,6 +2496,16 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 wave_sync();
             }
         }
+    }
+    if constexpr (MULTI) {  // on to the next step's slices of the inputs and outputs
+        const size_t ea = static_cast<size_t>(p.E) * A;
+        p.actions += ea;
+        if (p.order) p.order += ea;
+        if (p.image) p.image += ea * IMG;
+        if (p.direction) p.direction += ea;
+        if (p.reward) p.reward += ea;
+        if (p.terminated) p.terminated += ea;
+        if (p.truncated) p.truncated += ea;
     }
     } while (MULTI && ++t < p.T);  // steps of this launch
     if (MODE != MODE_OBS) {
