@@ -28,8 +28,8 @@ def find_masked_copies(asm_path):
         if not _LABEL.match(l.strip()):
             continue
         label, pending = l.strip().split(":")[0], []
-        for m in lines[i + 1:]:
-            t = m.split(";")[0].strip()
+        for j in range(i + 1, len(lines)):  # (an index, not a slice: listings run to millions of lines)
+            t = lines[j].split(";")[0].strip()
             if not t:
                 continue
             if _LABEL.match(t) or t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
