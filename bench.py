@@ -76,6 +76,7 @@ def measured_traffic(name, num_envs):
 # collectives run over gloo on host copies.  Everything else - sharding by env_id_offset, barriers, maximum over the
 # ranks, the statistics all-reduce and its check - is the code a real `--gpus N` run executes.
 REHEARSE = os.environ.get("MGRID_BENCH_REHEARSE") == "1"
+SUSTAINED_CLOCK_STEPS = 1000  # untimed steps (W included) before the first timed one, see gpu_leg()
 
 
 def local_device_index():
@@ -138,6 +139,12 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
                 env.step_n(actions[(t % 2) * T:(t % 2 + 1) * T], out=outn)
 
     run(warmup if T == 1 else max(T, warmup // T * T))
+    # A GPU that has idled through the set-up takes some 25 ms of work to reach its sustained clocks (measured: the
+    # same step is 5 % slower in the first milliseconds).  With a short warm-up the timed steps would be measured on
+    # the way up, so further UNTIMED steps bring it there first; the line reports them (`extra_warmup_steps`).
+    extra_warmup = max(0, SUSTAINED_CLOCK_STEPS - warmup) // max(1, T) * max(1, T)
+    if extra_warmup:
+        run(extra_warmup, warmup)
     graphed = None
     if graph:
         # replay `ring` launches per graph launch; the step kernel keeps no host-side state
@@ -186,7 +193,8 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
             distributed.allreduce_stats(stats)
         all_reduce_(check, torch.distributed.ReduceOp.SUM)
     out = dict(spec=spec, name=name, agents=agents, num_envs=num_envs, wall=walls[mid], gpu_s=gpus[mid],
-               walls=walls, stats=stats.cpu().numpy(), check=check.cpu().tolist(), max_steps=spec["max_steps"])
+               walls=walls, stats=stats.cpu().numpy(), check=check.cpu().tolist(), max_steps=spec["max_steps"],
+               extra_warmup=extra_warmup)
     env.close()
     return out
 
@@ -482,6 +490,7 @@ def main(argv=None):
                                f"over [0, {r['max_steps']})",
                    "baseline_config": args.config, "envs_per_gpu": num_envs, "agents": agents,
                    "grid": [spec["width"], spec["height"]], "steps_per_launch": T,
+                   "extra_warmup_steps": r["extra_warmup"],
                    "launch": "hip_graph" if args.graph else "eager", "parallelism": f"env-shard x{world}"},
         "rccl_ranks": (None if REHEARSE else torch.distributed.get_world_size()) if world > 1 else 1,
         "collective_check": {"ranks_seen": ranks_seen, "steps_sum": steps_sum, "launches_sum": launches_sum,
