@@ -95,9 +95,11 @@ def all_reduce_(t, op):
 
 
 def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one_hot=False, repeats=1,
-            steps_per_launch=1, **override):
+            steps_per_launch=1, stream_shards=1, **override):
     """Times `repeats` runs of `steps` step launches each (every run bracketed by a barrier and a device
-    synchronisation on both sides, maximum over ranks) and returns the median run."""
+    synchronisation on both sides, maximum over ranks) and returns the median run.  With `stream_shards` S > 1 the
+    rank's batch is held as S slices that step on streams of their own without waiting for each other
+    (mg_step_shards): a step is then S launches, and the device time is taken from events on those streams."""
     import torch
 
     from multigrid_amd import _lib, envs, layouts
@@ -107,8 +109,15 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **dict(kw, **override))
     dev = torch.device("cuda", local_device_index())
     torch.cuda.set_device(dev)
-    env = BatchedMultiGrid(spec, num_envs, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
-                           env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
+    S = max(1, stream_shards)
+    if S > 1:
+        from multigrid_amd.sharded import StreamShardedMultiGrid
+        assert steps_per_launch == 1
+        env = StreamShardedMultiGrid(spec, num_envs, shards=S, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
+                                     env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
+    else:
+        env = BatchedMultiGrid(spec, num_envs, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
+                               env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
     grids, ags, metas, _ = layouts.make_pool(gen, args.layouts, seed0=0)
     env.upload_layouts(grids, ags, metas)
     env.reset()
@@ -129,8 +138,19 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
                           terminated=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
                           truncated=torch.empty((T, e, a), dtype=torch.uint8, device=dev))
 
+    shard_graphs = []
+
     def run(n, t0=0):
-        if T == 1:
+        if shard_graphs:  # every slice replays its own graph of `ring` launches on its own stream
+            assert n % ring == 0
+            for _ in range(n // ring):
+                for k, gr in enumerate(shard_graphs):
+                    with torch.cuda.stream(env.streams[k]):
+                        gr.replay()
+        elif S > 1:  # the actions are complete and nothing here reads the outputs: the slices run free
+            for t in range(n):
+                env.step(actions[(t0 + t) % ring], fork=False, join=False)
+        elif T == 1:
             for t in range(n):
                 env.step(actions[(t0 + t) % ring])
         else:
@@ -146,7 +166,17 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     if extra_warmup:
         run(extra_warmup, warmup)
     graphed = None
-    if graph:
+    if graph and S > 1:
+        torch.cuda.synchronize(dev)
+        for k, (sh, (lo, hi)) in enumerate(zip(env.shards, env.bounds)):
+            gr = torch.cuda.CUDAGraph()
+            mine = [actions[t, lo:hi] for t in range(ring)]
+            with torch.cuda.graph(gr, stream=env.streams[k]):
+                for t in range(ring):
+                    sh.step(mine[t])
+            shard_graphs.append(gr)
+        torch.cuda.synchronize(dev)
+    elif graph:
         # replay `ring` launches per graph launch; the step kernel keeps no host-side state
         graphed = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream(device=dev)
@@ -162,19 +192,23 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        on = env.streams if S > 1 else [torch.cuda.current_stream(dev)]  # the streams the kernels are launched on
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in on]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in on]
         wall0 = time.perf_counter()
-        ev0.record()
+        for ev, st in zip(ev0, on):
+            ev.record(st)
         if graphed is not None:
             assert steps % ring == 0
             for _ in range(steps // ring):
                 graphed.replay()
         else:
             run(steps, warmup + rep * steps)
-        ev1.record()
+        for ev, st in zip(ev1, on):
+            ev.record(st)
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - wall0
-        gpu_s = ev0.elapsed_time(ev1) / 1e3
+        gpu_s = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / 1e3
         if world > 1:
             torch.distributed.barrier()
             t = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
@@ -364,6 +398,9 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the launches from a HIP graph")
     ap.add_argument("--fused", type=int, default=1, metavar="T",
                     help="T > 1: one fused launch per T steps (mg_step_n) instead of one launch per step")
+    ap.add_argument("--stream-shards", type=int, default=1, metavar="S",
+                    help="S > 1: every rank holds its batch as S slices stepping on streams of their own "
+                         "(mg_step_shards), none waiting for the others")
     ap.add_argument("--repeats", type=int, default=0, help="timed runs of --steps launches; the median is reported "
                     "(default: 5 when --steps < 200, else 1)")
     ap.add_argument("--no-overlap", action="store_true", help="allow_agent_overlap=False (agents block each other)")
@@ -466,8 +503,9 @@ def main(argv=None):
     num_envs = args.envs or (per_gpu if args.scaling == "weak" else max(1, total // world))
     repeats = args.repeats or (5 if args.steps < 200 else 1)
     T = max(1, args.fused)
+    S = max(1, args.stream_shards)
     r = gpu_leg(args, args.config, num_envs, rank, world, args.steps, args.warmup, graph=args.graph, repeats=repeats,
-                steps_per_launch=T, **({"allow_agent_overlap": False} if args.no_overlap else {}))
+                steps_per_launch=T, stream_shards=S, **({"allow_agent_overlap": False} if args.no_overlap else {}))
     spec = r["spec"]
     total_agent_steps = world * num_envs * agents * args.steps
     value = total_agent_steps / r["wall"]
@@ -489,7 +527,7 @@ def main(argv=None):
                                f"same-step auto-reset from {args.layouts} layouts, start step counts scattered "
                                f"over [0, {r['max_steps']})",
                    "baseline_config": args.config, "envs_per_gpu": num_envs, "agents": agents,
-                   "grid": [spec["width"], spec["height"]], "steps_per_launch": T,
+                   "grid": [spec["width"], spec["height"]], "steps_per_launch": T, "stream_shards": S,
                    "extra_warmup_steps": r["extra_warmup"],
                    "launch": "hip_graph" if args.graph else "eager", "parallelism": f"env-shard x{world}"},
         "rccl_ranks": (None if REHEARSE else torch.distributed.get_world_size()) if world > 1 else 1,
@@ -499,7 +537,9 @@ def main(argv=None):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from profiles/",
                      "frac_counter_bytes": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "kernel": "mg_tile_kernel" if T == 1 else "mg_tile_kernel (multi-step variant)",
+                     "kernel": ("mg_tile_kernel" if T == 1 else "mg_tile_kernel (multi-step variant)") +
+                               (f", {S} launches side by side on {S} streams per step: bytes of all of them over the "
+                                f"time of a whole-batch step" if S > 1 else ""),
                      "algorithmic_bytes_per_env_step": bytes_step, "launch_us": launch_s * 1e6,
                      "us_per_step": launch_s / T * 1e6},
         "episode_stats": {"episodes": int(r["stats"][0]), "mean_length": float(r["stats"][1]) / max(1, int(r["stats"][0])),
@@ -526,6 +566,7 @@ def main(argv=None):
             tr = measured_traffic(n2, e2) if not label else None
             extra.append({"baseline_config": cid, "workload": f"{n2}, {a2} agents, {e2} envs" + (", " + label if label else ""),
                           "value": e2 * a2 * n_steps / x["wall"], "launch_us": ls * 1e6, "steps_per_launch": Tx,
+                          "stream_shards": kw.get("stream_shards", 1),
                           "us_per_step": ls / Tx * 1e6, "algorithmic_bytes_per_env_step": b2,
                           "roofline_frac": e2 * b2 * Tx / ls / 1e9 / HBM_PEAK_GBS,
                           # a fused launch needs fewer bytes per step (the state travels once per launch): the same
@@ -552,7 +593,25 @@ def main(argv=None):
             for Tx in (8, 64):
                 add(cid, CONFIGS[cid][2], f"one launch per {Tx} steps (mg_step_n)", 384 if cid != 5 else 128, 64,
                     steps_per_launch=Tx)
+        # the same one-step launches with the batch held as two slices on two streams (mg_step_shards): the start
+        # and the drain of one slice's launch overlap the other's work
+        for cid, e2 in ((5, CONFIGS[5][2]), (4, CONFIGS[4][3]), (4, CONFIGS[4][2]), (3, CONFIGS[3][2])):
+            add(cid, e2, "2 stream shards (mg_step_shards)", 400, 48, stream_shards=2)
+        add(5, CONFIGS[5][2], "allow_agent_overlap=False, 2 stream shards (mg_step_shards)", 400, 48,
+            stream_shards=2, allow_agent_overlap=False)
+        for cid in (3, 4):
+            add(cid, CONFIGS[cid][2], "2 stream shards, each replaying a HIP graph of 16 launches", 400, 48,
+                stream_shards=2, graph=True)
         line["other_configs"] = extra
+        # the headline workload again, held as two slices on two streams: the same kernel and the same results,
+        # whole-batch steps no longer separated by the drain of one launch and the start of the next
+        if S == 1 and T == 1 and not args.graph and not args.no_overlap:
+            twin = next((x for x in extra if x["baseline_config"] == args.config and x["stream_shards"] == 2 and
+                         x["workload"].startswith(f"{name}, {agents} agents, {num_envs} envs, 2 stream")), None)
+            if twin:
+                line["stream_sharded"] = {k: twin[k] for k in ("workload", "value", "stream_shards", "us_per_step",
+                                                               "roofline_frac")}
+                line["stream_sharded"]["speedup_over_one_stream"] = twin["value"] / value
         line["config1_one_env"] = latency_one_env(args)
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_leg(args.config)

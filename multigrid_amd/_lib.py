@@ -19,12 +19,12 @@ MG_OK = 0
 KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY, KIND_COMPETITIVE = range(5)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
            "mg_set_reward_schemes",
-           "mg_reset", "mg_step", "mg_step_n", "mg_gen_obs", "mg_gen_obs_of_state", "mg_get_state", "mg_set_state",
+           "mg_reset", "mg_step", "mg_step_shards", "mg_step_n", "mg_gen_obs", "mg_gen_obs_of_state", "mg_get_state", "mg_set_state",
            "mg_stats")
 
 
@@ -33,7 +33,7 @@ class MgConfig(ctypes.Structure):
         "kind", "width", "height", "num_agents", "view_size", "max_steps", "see_through_walls",
         "allow_agent_overlap", "joint_reward", "success_any", "failure_any", "num_rooms",
         "num_envs", "device", "autoreset", "env_id_offset", "death_match", "per_agent_outputs")] + [
-        ("seed", ctypes.c_uint64)]
+        ("seed", ctypes.c_uint64), ("batch_envs", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class MgOut(ctypes.Structure):
@@ -109,6 +109,8 @@ def lib() -> ctypes.CDLL:
         L.mg_generate_layouts.argtypes = [vp, ctypes.POINTER(MgLayoutSpec), i32, ctypes.c_uint64]
         L.mg_reset.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_step.argtypes = [vp, vp, vp, ctypes.POINTER(MgOut), vp]
+        if hasattr(L, "mg_step_shards"):
+            L.mg_step_shards.argtypes = [ctypes.POINTER(vp), i32, vp, vp, ctypes.POINTER(MgOut), ctypes.POINTER(vp)]
         L.mg_step_n.argtypes = [vp, i32, vp, vp, ctypes.POINTER(MgOut), vp]
         L.mg_gen_obs.argtypes = [vp, ctypes.POINTER(MgOut), vp]
         L.mg_gen_obs_of_state.argtypes = [ctypes.POINTER(MgConfig), vp, vp, ctypes.POINTER(MgOut), vp]

@@ -61,9 +61,12 @@ class BatchedMultiGrid:
 
     def __init__(self, spec: dict, num_envs: int, device: int | str | torch.device = 0,
                  autoreset: int = _lib.AUTORESET_NONE, env_id_offset: int = 0, seed: int = 0,
-                 one_hot: bool = False, compact_image: bool = True):
+                 one_hot: bool = False, compact_image: bool = True, batch_envs: int = 0,
+                 out: Optional[StepOutput] = None):
         """``one_hot``: also return the image as ``OneHotObsWrapper`` encodes it (multigrid/wrappers.py:60-146),
-        written by the same launch; ``compact_image=False`` then skips the ``(V, V, 3)`` image."""
+        written by the same launch; ``compact_image=False`` then skips the ``(V, V, 3)`` image.  ``batch_envs``:
+        the size of the whole batch when this handle holds one slice of it (``sharded.StreamShardedMultiGrid``);
+        ``out``: tensors to adopt as the default outputs instead of allocating them."""
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedMultiGrid needs a ROCm GPU (no CPU fallback)")
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
@@ -80,7 +83,8 @@ class BatchedMultiGrid:
             failure_any=int(bool(spec["failure_any"])), num_rooms=int(spec.get("num_rooms", 0)),
             num_envs=self.E, device=dev.index or 0, autoreset=int(autoreset),
             env_id_offset=int(env_id_offset), death_match=int(bool(spec.get("death_match", False))),
-            per_agent_outputs=int(bool(spec.get("per_agent_outputs", True))), seed=int(seed))
+            per_agent_outputs=int(bool(spec.get("per_agent_outputs", True))), seed=int(seed),
+            batch_envs=int(batch_envs))
         self._h = ctypes.c_void_p()
         check(_lib.lib().mg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         if int(spec["kind"]) == _lib.KIND_COMPETITIVE:  # reward_schemes of multigrid/envs/__init__.py:100-108
@@ -89,7 +93,7 @@ class BatchedMultiGrid:
                 raise ValueError(f"reward_schemes must be [{self.A}][4], got {rs.shape}")
             check(_lib.lib().mg_set_reward_schemes(self._h, rs.ctypes.data), self._h)
         e, a, v = self.E, self.A, self.V
-        self.out = StepOutput(
+        self.out = out if out is not None else StepOutput(
             image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev) if compact_image or not one_hot else None,
             direction=torch.zeros((e, a), dtype=torch.uint8, device=dev),
             reward=torch.zeros((e, a), dtype=torch.float32, device=dev),

@@ -3099,6 +3099,7 @@ int configure(MgEnv *h, const MgConfig &c) {
         return fail(nullptr, MG_EINVAL, "view_size %d not supported (3, 5 or 7)", c.view_size);
     if (c.max_steps < 1) return fail(nullptr, MG_EINVAL, "max_steps must be positive");
     if (c.num_envs < 1) return fail(nullptr, MG_EINVAL, "num_envs must be positive");
+    if (c.batch_envs < 0) return fail(nullptr, MG_EINVAL, "batch_envs must not be negative");
     if (c.autoreset < 0 || c.autoreset > MG_AUTORESET_NEXT_STEP)
         return fail(nullptr, MG_EINVAL, "unknown autoreset mode %d", c.autoreset);
     if (c.kind == MG_KIND_LOCKEDHALLWAY && (c.num_rooms < 1 || c.num_rooms > 6))
@@ -3182,13 +3183,16 @@ int configure(MgEnv *h, const MgConfig &c) {
     // per wavefront balance lane use against LDS-limited occupancy; with the lane-per-agent act phase
     // 16 are enough and leave room for more wavefronts per CU, and one full sub-tile of 8 agents x 8
     // environments is (slightly) better still.
+    // A handle that holds one slice of a larger batch (batch_envs, see mg_step_shards) runs beside the other
+    // slices' launches: its tiles are shaped for the whole batch, not for the slice.
+    const int shape_envs = std::max(c.num_envs, c.batch_envs);
     int ne = 64 / c.num_agents;
     const int want_waves = 2048;
-    while (ne > 1 && (c.num_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
+    while (ne > 1 && (shape_envs + ne - 1) / ne < want_waves && ne * c.num_agents > 16) ne = (ne + 1) / 2;
     while (ne > 1 && lds_for(ne, 1) > 40 * 1024) --ne;
     int g = 1;
     const int et_target = c.num_agents >= 6 ? (c.num_agents <= 8 ? 8 : 16) : 32;
-    while ((g + 1) * ne <= et_target && (c.num_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
+    while ((g + 1) * ne <= et_target && (shape_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
     if (const char *ev = getenv("MGRID_STREAM")) h->force_stream = atoi(ev) != 0;  // tuning override: "0" / "1"
@@ -3525,6 +3529,49 @@ int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const u
         const int rc = mg_step(h, actions_dev ? actions_dev + t * per : nullptr, order_dev ? order_dev + t * per : nullptr,
                                out ? &o : nullptr, stream);
         if (rc != MG_OK) return rc;
+    }
+    return MG_OK;
+}
+
+int mg_step_shards(const MgHandle *shards, int32_t num_shards, const uint8_t *actions_dev, const uint8_t *order_dev,
+                   const MgOut *out, void *const *streams) {
+    if (!shards || num_shards < 1 || !shards[0]) return fail(nullptr, MG_EINVAL, "mg_step_shards: no shards");
+    if (!actions_dev) return fail(shards[0], MG_EINVAL, "mg_step_shards: actions_dev is null");
+    // the shards must be consecutive slices of one batch on one device: the same results as one handle holding it all
+    const MgConfig &c0 = shards[0]->cfg;
+    int64_t first = 0;
+    for (int32_t k = 0; k < num_shards; ++k) {
+        const MgHandle h = shards[k];
+        if (!h) return fail(shards[0], MG_EINVAL, "mg_step_shards: shard %d is null", k);
+        const MgConfig &c = h->cfg;
+        if (c.num_agents != c0.num_agents || c.view_size != c0.view_size || c.device != c0.device)
+            return fail(shards[0], MG_EINVAL, "mg_step_shards: shard %d differs from shard 0 in agents, view size or device", k);
+        if (static_cast<int64_t>(c.env_id_offset) != static_cast<int64_t>(c0.env_id_offset) + first)
+            return fail(shards[0], MG_EINVAL, "mg_step_shards: shard %d has env_id_offset %d, its slice starts at %lld", k,
+                        c.env_id_offset, static_cast<long long>(c0.env_id_offset + first));
+        for (int32_t j = 0; j < k; ++j)
+            if (shards[j] == h) return fail(shards[0], MG_EINVAL, "mg_step_shards: shard %d is listed twice", k);
+        first += c.num_envs;
+    }
+    const size_t a = static_cast<size_t>(c0.num_agents), img = 3u * c0.view_size * c0.view_size;
+    size_t at = 0;  // agents before this shard's slice
+    for (int32_t k = 0; k < num_shards; ++k) {
+        MgOut o{};
+        if (out) {
+            o.image_dev = out->image_dev ? out->image_dev + at * img : nullptr;
+            o.onehot_dev = out->onehot_dev ? out->onehot_dev + at * img * (OH_DIM / 3) : nullptr;
+            o.direction_dev = out->direction_dev ? out->direction_dev + at : nullptr;
+            o.reward_dev = out->reward_dev ? out->reward_dev + at : nullptr;
+            o.terminated_dev = out->terminated_dev ? out->terminated_dev + at : nullptr;
+            o.truncated_dev = out->truncated_dev ? out->truncated_dev + at : nullptr;
+        }
+        const int rc = mg_step(shards[k], actions_dev + at, order_dev ? order_dev + at : nullptr, out ? &o : nullptr,
+                               streams ? streams[k] : nullptr);
+        if (rc != MG_OK) {
+            if (k > 0) fail(shards[0], rc, "mg_step_shards: shard %d: %s", k, shards[k]->err.c_str());
+            return rc;
+        }
+        at += static_cast<size_t>(shards[k]->cfg.num_envs) * a;
     }
     return MG_OK;
 }

@@ -1,0 +1,176 @@
+"""``StreamShardedMultiGrid``: one batch of environments held as S slices that step on HIP streams of their own.
+
+Environments are independent (multigrid/base.py:364-408 touches one environment's state only), but launches on one
+stream are not: step t + 1 of every environment waits until the slowest wavefront of step t has drained.  Held as
+S handles on S streams (``mg_step_shards``), a slice waits only for itself, so the start and the drain of one
+slice's launch overlap the other slices' work.  The reference runs groups of environments side by side in the same
+spirit, as rollout workers (multigrid/utils/training_utilis.py:273) and as a vector of environments
+(multigrid/scripts/train_ppo_cleanrl.py:366).
+
+Results are those of one ``BatchedMultiGrid`` of the same size (layout choice and agent order depend on the global
+environment index): whole-batch tensors in, whole-batch tensors out, every slice reading and writing its part.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .batched import BatchedMultiGrid, StepOutput, _ptr
+
+ALIGN_ENVS = 64  # slices start at a multiple of this: their parts of the output arrays stay 16-byte aligned
+
+
+class StreamShardedMultiGrid:
+    def __init__(self, spec: dict, num_envs: int, shards: int = 2, device: int | str | torch.device = 0,
+                 autoreset: int = _lib.AUTORESET_NONE, env_id_offset: int = 0, seed: int = 0,
+                 one_hot: bool = False, compact_image: bool = True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StreamShardedMultiGrid needs a ROCm GPU (no CPU fallback)")
+        if shards < 1:
+            raise ValueError("shards must be positive")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.device, self.spec = dev, dict(spec)
+        self.E, self.A, self.V = int(num_envs), int(spec["num_agents"]), int(spec["view_size"])
+        self.W, self.H = int(spec["width"]), int(spec["height"])
+        per = -(-self.E // shards)
+        per = -(-per // ALIGN_ENVS) * ALIGN_ENVS
+        self.bounds = [(lo, min(lo + per, self.E)) for lo in range(0, self.E, per)]
+        e, a, v = self.E, self.A, self.V
+        self.out = StepOutput(
+            image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev) if compact_image or not one_hot else None,
+            direction=torch.zeros((e, a), dtype=torch.uint8, device=dev),
+            reward=torch.zeros((e, a), dtype=torch.float32, device=dev),
+            terminated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
+            truncated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
+            onehot=torch.zeros((e, a, v, v, _lib.ONE_HOT_DIM), dtype=torch.uint8, device=dev) if one_hot else None)
+        self._mgout = BatchedMultiGrid._make_out(self.out)
+        self.shards: List[BatchedMultiGrid] = []
+        self.streams: List[torch.cuda.Stream] = []
+        for lo, hi in self.bounds:
+            self.shards.append(BatchedMultiGrid(
+                spec, hi - lo, device=dev, autoreset=autoreset, env_id_offset=env_id_offset + lo, seed=seed,
+                one_hot=one_hot, compact_image=compact_image, batch_envs=self.E, out=self._slice(self.out, lo, hi)))
+            self.streams.append(torch.cuda.Stream(device=dev))
+        n = len(self.shards)
+        self._handles = (ctypes.c_void_p * n)(*[s._h.value for s in self.shards])
+        self._stream_ptrs = (ctypes.c_void_p * n)(*[s.cuda_stream for s in self.streams])
+        self.num_layouts = 0
+
+    @staticmethod
+    def _slice(o: StepOutput, lo: int, hi: int) -> StepOutput:
+        cut = lambda t: None if t is None else t[lo:hi]
+        return StepOutput(cut(o.image), cut(o.direction), cut(o.reward), cut(o.terminated), cut(o.truncated),
+                          cut(o.onehot))
+
+    # -- ordering between the caller's stream and the slices' streams -------------------------
+    def fork(self):
+        """The slices' streams wait for everything queued so far on the current stream (e.g. the kernel that
+        wrote the actions)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        for s in self.streams:
+            s.wait_event(ev)
+
+    def join(self, shard: Optional[int] = None):
+        """The current stream waits for everything queued so far on the slices' streams (or on one of them)."""
+        cur = torch.cuda.current_stream(self.device)
+        for k in (range(len(self.streams)) if shard is None else (shard,)):
+            cur.wait_stream(self.streams[k])
+
+    def _each(self, fn):
+        """Runs ``fn(k, shard, lo, hi)`` for every slice on its own stream, ordered after and before the current one."""
+        self.fork()
+        res = []
+        for k, (sh, (lo, hi)) in enumerate(zip(self.shards, self.bounds)):
+            with torch.cuda.stream(self.streams[k]):
+                res.append(fn(k, sh, lo, hi))
+        self.join()
+        return res
+
+    # -- API (as BatchedMultiGrid) -------------------------------------------------------------
+    def upload_layouts(self, grids: np.ndarray, agents: np.ndarray, meta: Optional[np.ndarray] = None):
+        for sh in self.shards:
+            sh.upload_layouts(grids, agents, meta)
+        self.num_layouts = self.shards[0].num_layouts
+
+    def generate_layouts(self, gen, n: int, seed: int = 0):
+        for sh in self.shards:  # layout l depends on (seed, l) only: every slice draws the same pool
+            sh.generate_layouts(gen, n, seed)
+        self.num_layouts = int(n)
+
+    def reset(self, layout_idx=None, mask=None) -> StepOutput:
+        """``MultiGridEnv.reset`` (multigrid/base.py:310) for all (or the masked) environments; the current stream
+        has waited for it on return."""
+        li = None if layout_idx is None else torch.as_tensor(layout_idx).to(device=self.device, dtype=torch.int32)
+        mk = None if mask is None else torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8)
+        self._each(lambda k, sh, lo, hi: sh.reset(None if li is None else li[lo:hi], None if mk is None else mk[lo:hi]))
+        return self.out
+
+    def step(self, actions, order=None, fork: bool = True, join: bool = True) -> StepOutput:
+        """``MultiGridEnv.step`` (multigrid/base.py:364) for every environment: one launch per slice, each on the
+        slice's stream.  ``fork``: the launches wait for what the current stream holds so far (the producer of
+        ``actions``); ``join``: the current stream then waits for the launches, so that anything queued on it
+        afterwards sees the outputs.  With both (the default) this is ``BatchedMultiGrid.step`` in S pieces, correct
+        for any caller and no faster.  The slices run ahead of each other only with ``join=False``: the caller then
+        consumes slice k on ``streams[k]`` (or after ``join(k)``), and may pass ``fork=False`` when the actions
+        are known to be complete."""
+        sh0 = self.shards[0]
+        act = sh0._dev_u8(actions, (self.E, self.A)) if not (
+            isinstance(actions, torch.Tensor) and actions.dtype == torch.uint8 and actions.device == self.device and
+            actions.is_contiguous() and actions.shape == (self.E, self.A)) else actions
+        od = None if order is None else sh0._dev_u8(order, (self.E, self.A))
+        if fork:
+            self.fork()
+            for s in self.streams:  # the allocator must not hand these out again before the slices have read them
+                act.record_stream(s)
+                if od is not None:
+                    od.record_stream(s)
+        check(_lib.lib().mg_step_shards(self._handles, len(self.shards), _ptr(act), _ptr(od),
+                                        ctypes.byref(self._mgout), self._stream_ptrs), sh0._h)
+        if join:
+            self.join()
+        return self.out
+
+    def gen_obs(self) -> StepOutput:
+        """``MultiGridEnv.gen_obs`` (multigrid/base.py:410)."""
+        self._each(lambda k, sh, lo, hi: sh.gen_obs())
+        return self.out
+
+    def get_state(self):
+        parts = self._each(lambda k, sh, lo, hi: sh.get_state())
+        return {key: torch.cat([p[key] for p in parts]) for key in parts[0]}
+
+    def set_state(self, grid=None, agents=None, meta=None, steps=None, flags=None):
+        dev = self.device
+        t = lambda x: None if x is None else torch.as_tensor(x).to(device=dev)
+        g, a, m, s, f = t(grid), t(agents), t(meta), t(steps), t(flags)
+        cut = lambda x, lo, hi: None if x is None else x[lo:hi]
+        self._each(lambda k, sh, lo, hi: sh.set_state(cut(g, lo, hi), cut(a, lo, hi), cut(m, lo, hi), cut(s, lo, hi),
+                                                      cut(f, lo, hi)))
+
+    def stats(self) -> torch.Tensor:
+        """int64[8] episode statistics of the whole batch: sums over the slices; entry 5 (steps taken) is the
+        same for every slice and reported once."""
+        parts = torch.stack(self._each(lambda k, sh, lo, hi: sh.stats()))
+        total = parts.sum(dim=0)
+        total[5] = parts[:, 5].max()
+        return total
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        for sh in self.shards:
+            sh.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

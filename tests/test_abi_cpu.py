@@ -41,6 +41,10 @@ def test_bad_arguments_fail_without_a_gpu():
     cfg = _lib.MgConfig(kind=3, width=13, height=9, num_agents=2, view_size=7, max_steps=10, num_envs=4, num_rooms=8)
     assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"LockedHallway" in L.mg_last_error(None)
+    cfg = _lib.MgConfig(kind=0, width=8, height=8, num_agents=2, view_size=7, max_steps=10, num_envs=4, batch_envs=-1)
+    assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"batch_envs" in L.mg_last_error(None)
+    assert L.mg_step_shards(None, 0, None, None, None, None) == -1  # an empty shard list
+    assert b"mg_step_shards" in L.mg_last_error(None)
 
 
 def test_product_never_imports_the_oracle():

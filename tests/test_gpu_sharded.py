@@ -1,0 +1,123 @@
+"""One batch held as stream shards (mg_step_shards, multigrid_amd/sharded.py) steps exactly like one handle holding
+all of it, and like the C oracle - whether the slices are joined after every step or run ahead of each other."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from multigrid_amd import envs, layouts
+from test_gpu_batch import CASES, compare, compare_state, rand_inputs
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("image", "direction", "reward", "terminated", "truncated")
+
+
+def make_pair(case, e, shards, **kw):
+    from multigrid_amd.batched import BatchedMultiGrid
+    from multigrid_amd.sharded import StreamShardedMultiGrid
+    name, agents, extra = CASES[case]
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))
+    pool = layouts.make_pool(gen, 48, seed0=11)
+    whole = BatchedMultiGrid(spec, e, device=0, **kw)
+    cut = StreamShardedMultiGrid(spec, e, shards=shards, device=0, **kw)
+    for x in (whole, cut):
+        x.upload_layouts(pool[0], pool[1], pool[2])
+    return spec, pool, whole, cut
+
+
+@pytest.mark.parametrize("case,e,shards", [("cfg5", 3000, 2), ("cfg4", 2500, 3), ("cfg3", 1111, 2), ("cfg5_nooverlap", 1500, 4),
+                                           ("cfg2", 100, 2)])
+def test_shards_equal_one_batch(case, e, shards):
+    """Ragged slices (the last one shorter, sizes that are no multiple of a tile), on-device agent order, same-step
+    auto-reset with scattered start steps: every output of every step and the statistics match one handle's."""
+    import torch
+    spec, pool, whole, cut = make_pair(case, e, shards, autoreset=1, seed=5, env_id_offset=640)
+    assert sum(hi - lo for lo, hi in cut.bounds) == e and len(cut.shards) <= shards
+    a = spec["num_agents"]
+    ow, oc = whole.reset(), cut.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(ow.image, oc.image) and torch.equal(ow.direction, oc.direction)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    steps0 = torch.randint(0, spec["max_steps"], (e,), generator=g, device="cuda:0", dtype=torch.int32)
+    whole.set_state(steps=steps0)
+    cut.set_state(steps=steps0)
+    for t in range(60):
+        acts = torch.randint(0, 7, (e, a), generator=g, device="cuda:0", dtype=torch.uint8)
+        w, c = whole.step(acts), cut.step(acts)
+        torch.cuda.synchronize()
+        for f in FIELDS:
+            assert torch.equal(getattr(w, f), getattr(c, f)), f"{case} step {t} {f}"
+    sw, sc = whole.stats().cpu().numpy(), cut.stats().cpu().numpy()
+    assert sw[0] > 0 and (sw == sc).all(), (sw, sc)
+    st_w, st_c = whole.get_state(), cut.get_state()
+    for k in st_w:
+        assert torch.equal(st_w[k], st_c[k]), k
+    whole.close()
+    cut.close()
+
+
+def test_free_running_shards_against_oracle():
+    """The slices step without waiting for each other (no fork, no join: the bench's mode) through inputs that are
+    complete beforehand; outputs go to per-step tensors and are compared with the C oracle afterwards."""
+    import torch
+    from multigrid_amd.sharded import StreamShardedMultiGrid
+    from oracle.coracle import BatchOracle
+    from multigrid_amd.batched import StepOutput
+    name, agents, extra = CASES["cfg4"]
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))
+    pool = layouts.make_pool(gen, 32, seed0=3)
+    e, a, v, n = 2000, agents, 7, 40
+    env = StreamShardedMultiGrid(spec, e, shards=2, device=0)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    ora = BatchOracle(spec, e)
+    rng = np.random.default_rng(8)
+    idx = rng.integers(0, 32, size=e).astype(np.int32)
+    out = env.reset(layout_idx=idx)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    ins = [rand_inputs(rng, e, a) for _ in range(n)]
+    acts = torch.as_tensor(np.stack([i[0] for i in ins])).cuda()
+    order = torch.as_tensor(np.stack([i[1] for i in ins])).cuda()
+    torch.cuda.synchronize()
+    # every step writes its own slice of [n, ...] tensors: point the shards' output block there step by step
+    keep = StepOutput(image=torch.zeros((n, e, a, v, v, 3), dtype=torch.uint8, device="cuda:0"),
+                      direction=torch.zeros((n, e, a), dtype=torch.uint8, device="cuda:0"),
+                      reward=torch.zeros((n, e, a), dtype=torch.float32, device="cuda:0"),
+                      terminated=torch.zeros((n, e, a), dtype=torch.uint8, device="cuda:0"),
+                      truncated=torch.zeros((n, e, a), dtype=torch.uint8, device="cuda:0"))
+    torch.cuda.synchronize()
+    from multigrid_amd.batched import BatchedMultiGrid
+    for t in range(n):
+        env._mgout = BatchedMultiGrid._make_out(StepOutput(keep.image[t], keep.direction[t], keep.reward[t],
+                                                           keep.terminated[t], keep.truncated[t]))
+        env.step(acts[t], order[t], fork=False, join=False)
+    env.synchronize()
+    for t in range(n):
+        o = ora.step(*ins[t])
+        compare(StepOutput(keep.image[t], keep.direction[t], keep.reward[t], keep.terminated[t], keep.truncated[t]),
+                o, f"free-running step {t}")
+    compare_state(env, ora, "free-running end")
+    env.close()
+
+
+def test_shard_list_is_checked():
+    """mg_step_shards refuses handles that are not consecutive slices of one batch."""
+    import torch
+    from multigrid_amd import _lib
+    from multigrid_amd.sharded import StreamShardedMultiGrid
+    name, agents, extra = CASES["cfg1"]
+    spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))
+    pool = layouts.make_pool(gen, 4, seed0=0)
+    env = StreamShardedMultiGrid(spec, 256, shards=2, device=0)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    env.reset()
+    acts = torch.zeros((256, agents), dtype=torch.uint8, device="cuda:0")
+    env.step(acts)
+    swapped = (ctypes.c_void_p * 2)(env._handles[1], env._handles[0])
+    rc = _lib.lib().mg_step_shards(swapped, 2, ctypes.c_void_p(acts.data_ptr()), None, ctypes.byref(env._mgout), None)
+    assert rc == -1 and b"env_id_offset" in _lib.lib().mg_last_error(ctypes.c_void_p(env._handles[1]))
+    twice = (ctypes.c_void_p * 2)(env._handles[0], env._handles[0])
+    assert _lib.lib().mg_step_shards(twice, 2, ctypes.c_void_p(acts.data_ptr()), None, ctypes.byref(env._mgout), None) == -1
+    assert _lib.lib().mg_step_shards(None, 0, None, None, None, None) == -1
+    torch.cuda.synchronize()
+    env.close()
