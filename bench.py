@@ -112,7 +112,6 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     S = max(1, stream_shards)
     if S > 1:
         from multigrid_amd.sharded import StreamShardedMultiGrid
-        assert steps_per_launch == 1
         env = StreamShardedMultiGrid(spec, num_envs, shards=S, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
                                      env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
     else:
@@ -131,12 +130,19 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     outn = None
     if T > 1:
         from multigrid_amd.batched import StepOutput
-        e, a, v = num_envs, agents, spec["view_size"]
-        outn = StepOutput(image=torch.empty((T, e, a, v, v, 3), dtype=torch.uint8, device=dev),
-                          direction=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
-                          reward=torch.empty((T, e, a), dtype=torch.float32, device=dev),
-                          terminated=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
-                          truncated=torch.empty((T, e, a), dtype=torch.uint8, device=dev))
+
+        def rollout_buffers(e):
+            a, v = agents, spec["view_size"]
+            return StepOutput(image=torch.empty((T, e, a, v, v, 3), dtype=torch.uint8, device=dev),
+                              direction=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
+                              reward=torch.empty((T, e, a), dtype=torch.float32, device=dev),
+                              terminated=torch.empty((T, e, a), dtype=torch.uint8, device=dev),
+                              truncated=torch.empty((T, e, a), dtype=torch.uint8, device=dev))
+        if S > 1:  # every slice has its own [T, E_k, ...] inputs and outputs
+            outn = [rollout_buffers(hi - lo) for lo, hi in env.bounds]
+            acts_k = [[actions[h * T:(h + 1) * T, lo:hi].contiguous() for h in range(2)] for lo, hi in env.bounds]
+        else:
+            outn = rollout_buffers(num_envs)
 
     shard_graphs = []
 
@@ -147,6 +153,10 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
                 for k, gr in enumerate(shard_graphs):
                     with torch.cuda.stream(env.streams[k]):
                         gr.replay()
+        elif S > 1 and T > 1:  # one fused launch of T steps per slice and stream
+            assert n % T == 0
+            for t in range(n // T):
+                env.step_n([ak[t % 2] for ak in acts_k], outs=outn, fork=False, join=False)
         elif S > 1:  # the actions are complete and nothing here reads the outputs: the slices run free
             for t in range(n):
                 env.step(actions[(t0 + t) % ring], fork=False, join=False)
@@ -602,6 +612,9 @@ def main(argv=None):
         for cid in (3, 4):
             add(cid, CONFIGS[cid][2], "2 stream shards, each replaying a HIP graph of 16 launches", 400, 48,
                 stream_shards=2, graph=True)
+        for cid in (3, 4, 5):
+            add(cid, CONFIGS[cid][2], "2 stream shards, one launch per 8 steps each (mg_step_n)", 384 if cid != 5 else 128,
+                64, stream_shards=2, steps_per_launch=8)
         line["other_configs"] = extra
         # the headline workload again, held as two slices on two streams: the same kernel and the same results,
         # whole-batch steps no longer separated by the drain of one launch and the start of the next

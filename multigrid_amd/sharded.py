@@ -136,6 +136,34 @@ class StreamShardedMultiGrid:
             self.join()
         return self.out
 
+    def step_n(self, actions, order=None, outs: Optional[List[StepOutput]] = None, fork: bool = True,
+               join: bool = True) -> List[StepOutput]:
+        """T consecutive steps, every slice taking them in ONE fused launch on its stream (``mg_step_n``).
+        ``actions`` (and ``order``) are either one ``[T, E, A]`` tensor of the whole batch - every slice then gets
+        a contiguous copy of its part - or a list with one contiguous ``[T, E_k, A]`` tensor per slice.  Returns one
+        ``StepOutput`` per slice with ``[T, E_k, ...]`` tensors (``bounds[k]`` names the slice's environments):
+        the slices' results are not interleaved in memory, their consumers work per slice anyway."""
+        def parts(x):
+            if x is None:
+                return [None] * len(self.shards)
+            if isinstance(x, (list, tuple)):
+                return list(x)
+            x = torch.as_tensor(x).to(device=self.device, dtype=torch.uint8)
+            return [x[:, lo:hi].contiguous() for lo, hi in self.bounds]
+        acts, ords = parts(actions), parts(order)  # (copies, if any, are made on the current stream)
+        if fork:
+            self.fork()
+        res = []
+        for k, sh in enumerate(self.shards):
+            for t in (acts[k], ords[k]):
+                if fork and isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(self.streams[k])
+            with torch.cuda.stream(self.streams[k]):
+                res.append(sh.step_n(acts[k], ords[k], out=None if outs is None else outs[k]))
+        if join:
+            self.join()
+        return res
+
     def gen_obs(self) -> StepOutput:
         """``MultiGridEnv.gen_obs`` (multigrid/base.py:410)."""
         self._each(lambda k, sh, lo, hi: sh.gen_obs())

@@ -121,3 +121,32 @@ def test_shard_list_is_checked():
     assert _lib.lib().mg_step_shards(None, 0, None, None, None, None) == -1
     torch.cuda.synchronize()
     env.close()
+
+
+@pytest.mark.parametrize("case,e", [("cfg5", 1500), ("cfg3", 2100)])
+def test_fused_steps_per_shard(case, e):
+    """step_n on shards: every slice takes T steps in one fused launch on its stream; together they equal T steps of
+    one handle holding the whole batch (on-device agent order, same-step auto-reset)."""
+    import torch
+    spec, pool, whole, cut = make_pair(case, e, 2, autoreset=1, seed=9)
+    a, T = spec["num_agents"], 9
+    whole.reset()
+    cut.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    steps0 = torch.randint(0, spec["max_steps"], (e,), generator=g, device="cuda:0", dtype=torch.int32)
+    whole.set_state(steps=steps0)
+    cut.set_state(steps=steps0)
+    for rnd in range(3):
+        acts = torch.randint(0, 7, (T, e, a), generator=g, device="cuda:0", dtype=torch.uint8)
+        w = whole.step_n(acts)
+        parts = cut.step_n(acts)
+        torch.cuda.synchronize()
+        for f in FIELDS:
+            got = torch.cat([getattr(p, f) for p in parts], dim=1)
+            assert torch.equal(getattr(w, f), got), f"{case} round {rnd} {f}"
+    st_w, st_c = whole.get_state(), cut.get_state()
+    for k in st_w:
+        assert torch.equal(st_w[k], st_c[k]), k
+    assert (whole.stats().cpu() == cut.stats().cpu()).all()
+    whole.close()
+    cut.close()
