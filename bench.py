@@ -274,8 +274,26 @@ def latency_one_env(args):
     torch.cuda.synchronize(dev)
     interval = (time.perf_counter() - t0) / 2000
     env.close()
+    # the same environment behind the reference's own API shape: dicts in, dicts of host arrays out
+    # (multigrid/base.py:364), one upload, two launches, one download and one wait per step
+    import numpy as np
+
+    from multigrid_amd import gym_api
+    genv = gym_api.make(name, agents=agents, agent_view_size=7, layout_rng=np.random.default_rng(0))
+    genv.reset(seed=0)
+    picks = np.random.default_rng(1).integers(0, 7, size=(1200, agents)).tolist()
+    for t in range(200):
+        genv.step(dict(enumerate(picks[t])))
+    t0 = time.perf_counter()
+    for t in range(200, 1200):
+        genv.step(dict(enumerate(picks[t])))
+        if genv.is_done():
+            genv.reset()
+    dict_step = (time.perf_counter() - t0) / 1000
+    genv.close()
     return dict(workload=f"{name}, {agents} agents, 1 env", sync_step_latency_us=statistics.median(lat) * 1e6,
-                back_to_back_launch_us=interval * 1e6, agent_steps_per_s=agents / interval)
+                back_to_back_launch_us=interval * 1e6, agent_steps_per_s=agents / interval,
+                dict_api_step_us=dict_step * 1e6, dict_api_agent_steps_per_s=agents / dict_step)
 
 
 def memory_rates(dev):

@@ -13,6 +13,7 @@ multigrid/rllib/__init__.py:47-76 and multigrid/pettingzoo/__init__.py:35-70 by 
 """
 from __future__ import annotations
 
+import ctypes
 from collections import defaultdict
 from typing import Any, Dict, Optional
 
@@ -20,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib, envs
-from .batched import BatchedMultiGrid
+from .batched import BatchedMultiGrid, StepOutput
 from .constants import COLOR_NAMES
 
 
@@ -81,14 +82,37 @@ class MultiGridEnv:
         self.num_agents = self.spec["num_agents"]
         self.max_steps = self.spec["max_steps"]
         self.width, self.height = self.spec["width"], self.spec["height"]
-        self._sim = BatchedMultiGrid(self.spec, 1, device=device, autoreset=_lib.AUTORESET_NONE)
+        # Everything a step returns lives in ONE device block (the launch's outputs are views into it) that comes
+        # back with one copy into pinned host memory; actions and agent order go up as one pinned block too: a
+        # step is one upload, one launch, one download and one wait.
+        a, v = self.num_agents, self.spec["view_size"]
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        n_img = a * v * v * 3
+        self._off = dict(image=0, direction=n_img, terminated=n_img + a, truncated=n_img + 2 * a,
+                         reward=(n_img + 3 * a + 3) // 4 * 4)
+        self._off["rows"] = self._off["reward"] + 4 * a  # agent rows of the post-step state, 8 bytes per agent
+        total = self._off["rows"] + 8 * a
+        self._out_dev = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self._out_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        self._out_np = self._out_host.numpy()
+        o, blk = self._off, self._out_dev
+        packed = StepOutput(image=blk[:n_img].view(1, a, v, v, 3), direction=blk[o["direction"]:o["direction"] + a].view(1, a),
+                            reward=blk[o["reward"]:o["rows"]].view(torch.float32).view(1, a),
+                            terminated=blk[o["terminated"]:o["terminated"] + a].view(1, a),
+                            truncated=blk[o["truncated"]:o["truncated"] + a].view(1, a))
+        self._in_host = torch.zeros((2, 1, a), dtype=torch.uint8).pin_memory()
+        self._in_np = self._in_host.numpy()
+        self._in_dev = torch.zeros((2, 1, a), dtype=torch.uint8, device=dev)
+        self._sim = BatchedMultiGrid(self.spec, 1, device=dev, autoreset=_lib.AUTORESET_NONE, out=packed)
+        self._layout0 = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._rows_ptr = ctypes.c_void_p(blk[o["rows"]:].data_ptr())
         # RandomMixin keeps the generator that existed at construction time (multigrid/base.py:153);
         # gym.Env.np_random is the same object until reset(seed) replaces it.
         self._np_random = layout_rng if layout_rng is not None else np.random.default_rng()
         self._layout_rng = self._np_random
         self.mission = Mission(self.spec["mission"])
         self.step_count = 0
-        self._terminated = np.zeros(self.num_agents, dtype=bool)
+        self._rows = np.zeros((self.num_agents, 8), dtype=np.uint8)
         self.agent_names = []
         for team, n in self.teams.items():
             self.agent_names += [f"{team}_{i}" for i in range(n)]
@@ -127,22 +151,18 @@ class MultiGridEnv:
         grid, agents, meta, mission = self._gen(mixin_rng=self._layout_rng, env_rng=self._np_random)
         self.mission = Mission(mission)
         self._sim.upload_layouts(grid[None], agents[None], meta[None])
-        out = self._sim.reset(layout_idx=np.zeros(1, np.int32))
+        self._sim.reset(layout_idx=self._layout0)
         self.step_count = 0
-        self._terminated[:] = False
-        return self._obs_dict(out), defaultdict(dict)
+        return self._obs_dict(self._fetch()), defaultdict(dict)
 
     def step(self, actions: Dict[int, int]):
         """multigrid/base.py:364-408 plus the environment's own step hook."""
         a = self.num_agents
-        acts = np.array([[int(actions[i]) for i in range(a)]], dtype=np.uint8)
-        if a == 1:  # base.py:457-461
-            order = np.zeros((1, 1), dtype=np.uint8)
-        else:
-            order = self._np_random.random(size=a).argsort()[None].astype(np.uint8)
-        out = self._sim.step(acts, order)
-        self.step_count += 1
-        rew = out.reward[0].cpu().numpy().astype(np.float64)
+        acts = [int(actions[i]) for i in range(a)]
+        # base.py:457-461
+        order = np.zeros(1, dtype=np.uint8) if a == 1 else self._np_random.random(size=a).argsort()
+        got = self._launch_step(acts, order)
+        rew = got["reward"].astype(np.float64)
         # The device returns float32.  Every reward of a step is a whole number of _reward() values
         # (multigrid/base.py:655-659; LockedHallway adds one per door, locked_hallway.py:207-211), so the
         # reference's double is recomputed here from the step count and that number.
@@ -153,37 +173,65 @@ class MultiGridEnv:
                 for _ in range(int(round(rew[i] / unit))):
                     total += unit
                 rew[i] = total
-        term = out.terminated[0].cpu().numpy().astype(bool)
-        trunc = out.truncated[0].cpu().numpy().astype(bool)
-        st = self._sim.get_state()
-        self._terminated = st["agents"][0, :, 3].cpu().numpy().astype(bool)
+        term, trunc = got["terminated"].astype(bool), got["truncated"].astype(bool)
         rewards = {i: (float(rew[i]) if rew[i] != 0 else 0) for i in range(a)}
         terminations = {i: np.bool_(term[i]) for i in range(a)}
         truncations = {i: bool(trunc[i]) for i in range(a)}
-        return self._obs_dict(out), rewards, terminations, truncations, defaultdict(dict)
+        return self._obs_dict(got), rewards, terminations, truncations, defaultdict(dict)
 
     def gen_obs(self):
         """multigrid/base.py:410-438."""
-        return self._obs_dict(self._sim.gen_obs())
+        self._sim.gen_obs()
+        return self._obs_dict(self._fetch())
 
     def is_done(self) -> bool:
         """multigrid/base.py:587-596."""
         return self.step_count >= self.max_steps or bool(self._terminated.all())
 
+    @property
+    def _terminated(self) -> np.ndarray:
+        """``agent_states.terminated`` (not always what ``step`` returned: LockedHallway's all-doors ending sets only
+        the returned flags, locked_hallway.py:213-215): column 3 of the agent rows that came back with the step."""
+        return self._rows[:, 3].astype(bool)
+
     def close(self):
         self._sim.close()
 
     # -- helpers ------------------------------------------------------------------------------------
-    def _obs_dict(self, out):
-        img = out.image[0].cpu().numpy().astype(np.int64)
-        direction = out.direction[0].cpu().numpy().astype(np.int64)
+    def _launch_step(self, acts, order):
+        """One upload (actions and order), the step launch, one download of everything it returned."""
+        self._in_np[0, 0, :] = acts
+        self._in_np[1, 0, :] = order
+        self._in_dev.copy_(self._in_host, non_blocking=True)
+        self._sim.step(self._in_dev[0], self._in_dev[1])
+        self.step_count += 1
+        return self._fetch()
+
+    def _fetch(self):
+        """The packed output block of the last launch as host arrays (copies: the pinned block is reused)."""
+        stream = torch.cuda.current_stream(self._out_dev.device)
+        # the agent rows of the state the launch left behind travel in the same block (is_done, agent_states)
+        _lib.check(_lib.lib().mg_get_state(self._sim._h, None, self._rows_ptr, None, None, None,
+                                           ctypes.c_void_p(stream.cuda_stream)), self._sim._h)
+        self._out_host.copy_(self._out_dev, non_blocking=True)
+        stream.synchronize()
+        a, v, o, h = self.num_agents, self.spec["view_size"], self._off, self._out_np
+        self._rows = h[o["rows"]:o["rows"] + 8 * a].reshape(a, 8).copy()
+        return dict(image=h[:o["direction"]].reshape(a, v, v, 3).astype(np.int64),
+                    direction=h[o["direction"]:o["direction"] + a].astype(np.int64),
+                    terminated=h[o["terminated"]:o["terminated"] + a].copy(),
+                    truncated=h[o["truncated"]:o["truncated"] + a].copy(),
+                    reward=h[o["reward"]:o["reward"] + 4 * a].view(np.float32).copy())
+
+    def _obs_dict(self, got):
+        img, direction = got["image"], got["direction"]
         return {i: {"image": img[i], "direction": direction[i], "mission": self.mission}
                 for i in range(self.num_agents)}
 
     @property
     def agent_states(self) -> np.ndarray:
         """(A, 9) rows in the reference's column order (multigrid/core/agent.py:266-275)."""
-        rows = self._sim.get_state()["agents"][0].cpu().numpy().astype(np.int64)
+        rows = self._sim.get_state()["agents"][0].cpu().numpy().astype(np.int64)  # (the state may have been set since)
         out = np.zeros((self.num_agents, 9), dtype=np.int64)
         out[:, 0], out[:, 1], out[:, 2] = 10, rows[:, 7], rows[:, 2]
         out[:, 3], out[:, 4], out[:, 5] = rows[:, 0], rows[:, 1], rows[:, 3]
@@ -246,13 +294,10 @@ class CompetativeRedBlueDoorEnv(MultiGridEnv):
                 acts[0, k] = int(act)
                 order.append(k)
         order += [k for k in range(a) if k not in order]
-        out = self._sim.step(acts, np.array([order], dtype=np.uint8))
-        self.step_count += 1
-        rew = out.reward[0].cpu().numpy().astype(np.float64)  # float32 on the device
-        term = out.terminated[0].cpu().numpy().astype(bool)
-        trunc = out.truncated[0].cpu().numpy().astype(bool)
-        self._terminated = self._sim.get_state()["agents"][0, :, 3].cpu().numpy().astype(bool)
-        obs = self._format_obs(self._obs_dict(out))
+        got = self._launch_step(acts[0], order)
+        rew = got["reward"].astype(np.float64)  # float32 on the device
+        term, trunc = got["terminated"].astype(bool), got["truncated"].astype(bool)
+        obs = self._format_obs(self._obs_dict(got))
         if self.training_scheme == "CTCE":  # :346-368
             rewards = {t: float(sum(rew[k] for k in m)) for t, m in self.team_members.items()}
             terminations = {t: bool(all(term[k] for k in m)) for t, m in self.team_members.items()}
