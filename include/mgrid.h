@@ -240,6 +240,18 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
 #define MG_NUM_STATS 8
 int mg_stats(MgHandle h, int64_t *stats_dev, void *stream);
 
+/* Per-environment episode statistics of a vector of environments after a step with MG_AUTORESET_SAME_STEP, by one
+ * launch: replaces gym.wrappers.RecordEpisodeStatistics around every environment of the reference's SyncVectorEnv
+ * (multigrid/scripts/train_ppo_cleanrl.py:173,366) and the `final_info` entries its training loop reads
+ * (:418-427, :522-527).  reward / terminated / truncated are the step's outputs ([E][A]); return_acc double[E][A] and
+ * length_acc int64[E] are the caller's running counters (in and out, zero at reset).  An environment's episode is
+ * over when all its agents are terminated or it is truncated: done[e] = 1, episode_return[e][*] and
+ * episode_length[e] take the counters (this step included) and the counters start again at zero; elsewhere done and
+ * the episode outputs are zero.  All pointers are device pointers on the stream's device; needs no handle. */
+int mg_episode_stats(int32_t num_envs, int32_t num_agents, const float *reward_dev, const uint8_t *terminated_dev,
+                     const uint8_t *truncated_dev, double *return_acc_dev, int64_t *length_acc_dev, uint8_t *done_dev,
+                     double *episode_return_dev, int64_t *episode_length_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2655,6 +2655,45 @@ __global__ void mg_stats_kernel(const int64_t *shards, int64_t *out, int64_t lau
     out[k] = s;
 }
 
+// Per-environment episode statistics of a vector of environments, one thread per environment: what
+// gym.wrappers.RecordEpisodeStatistics keeps around every environment of the reference's SyncVectorEnv
+// (multigrid/scripts/train_ppo_cleanrl.py:173,366) and what its training loop reads back as
+// info["final_info"][i]["episode"]["r" / "l"] (:418-427, :522-527).  An episode is over when every agent is
+// terminated or the environment is truncated; the step's outputs come from a same-step auto-reset launch, so the
+// counters start again at once.
+__global__ void mg_episode_stats_kernel(int E, int A, const float *reward, const uint8_t *terminated,
+                                        const uint8_t *truncated, double *ret, int64_t *len, uint8_t *done,
+                                        double *ep_ret, int64_t *ep_len) {
+    // A block owns 256 / A consecutive environments.  First one thread per environment reads its A flag bytes
+    // and decides whether the episode is over; then one thread per (environment, agent) element updates the
+    // per-agent arrays, so that consecutive lanes touch consecutive elements.
+    __shared__ uint8_t over_s[256];
+    const int epb = 256 / A;
+    const int e0 = blockIdx.x * epb;
+    const int t = threadIdx.x;
+    if (t < epb && e0 + t < E) {
+        const size_t at = static_cast<size_t>(e0 + t) * A;
+        bool all_term = true;
+        for (int i = 0; i < A; ++i) all_term = all_term && terminated[at + i] != 0;
+        over_s[t] = (all_term || truncated[at] != 0) ? 1 : 0;
+    }
+    __syncthreads();
+    const int le = t / A, i = t - le * A;
+    if (le >= epb || e0 + le >= E) return;
+    const int e = e0 + le;
+    const bool over = over_s[le] != 0;
+    const size_t idx = static_cast<size_t>(e) * A + i;
+    const double r = ret[idx] + static_cast<double>(reward[idx]);
+    ep_ret[idx] = over ? r : 0.0;
+    ret[idx] = over ? 0.0 : r;
+    if (i == 0) {
+        const int64_t n = len[e] + 1;
+        ep_len[e] = over ? n : 0;
+        len[e] = over ? 0 : n;
+        done[e] = over ? 1 : 0;
+    }
+}
+
 // ---- start states generated on the device ----------------------------------------------------------------
 //
 // The `_gen_grid` procedures of the four environment classes (multigrid/envs/empty.py:152-171,
@@ -3675,6 +3714,23 @@ int mg_dbg_buffer(MgHandle h, void *buf_dev, int *num_tiles) {
     return MG_OK;
 }
 #endif
+
+int mg_episode_stats(int32_t num_envs, int32_t num_agents, const float *reward_dev, const uint8_t *terminated_dev,
+                     const uint8_t *truncated_dev, double *return_acc_dev, int64_t *length_acc_dev, uint8_t *done_dev,
+                     double *episode_return_dev, int64_t *episode_length_dev, void *stream) {
+    if (num_envs < 1 || num_agents < 1 || num_agents > 256)
+        return fail(nullptr, MG_EINVAL, "mg_episode_stats: num_envs must be positive and num_agents 1..256");
+    if (!reward_dev || !terminated_dev || !truncated_dev || !return_acc_dev || !length_acc_dev || !done_dev ||
+        !episode_return_dev || !episode_length_dev)
+        return fail(nullptr, MG_EINVAL, "mg_episode_stats: null argument");
+    const int per_block = 256 / num_agents;
+    hipLaunchKernelGGL(mg_episode_stats_kernel, dim3((num_envs + per_block - 1) / per_block), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       num_envs, num_agents, reward_dev, terminated_dev, truncated_dev, return_acc_dev, length_acc_dev,
+                       done_dev, episode_return_dev, episode_length_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, MG_EHIP, "mg_episode_stats: %s", hipGetErrorString(e));
+    return MG_OK;
+}
 
 int mg_stats(MgHandle h, int64_t *stats_dev, void *stream) {
     if (!h) return MG_EINVAL;

@@ -21,6 +21,7 @@ dimension is dropped, which is the exact ``SyncVectorEnv`` shape; otherwise arra
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import numpy as np
@@ -50,6 +51,11 @@ class MultiGridVectorEnv:
         dev = self._sim.device
         self._ret = torch.zeros((self.num_envs, self.num_agents), dtype=torch.float64, device=dev)
         self._len = torch.zeros((self.num_envs,), dtype=torch.int64, device=dev)
+        # outputs of mg_episode_stats, two sets used in turn
+        self._ep_ret = torch.zeros((2, self.num_envs, self.num_agents), dtype=torch.float64, device=dev)
+        self._ep_len = torch.zeros((2, self.num_envs), dtype=torch.int64, device=dev)
+        self._done = torch.zeros((2, self.num_envs), dtype=torch.uint8, device=dev)
+        self._flip = 0
 
     # -- helpers ----------------------------------------------------------------------------------
     def _view(self, t: torch.Tensor):
@@ -87,22 +93,23 @@ class MultiGridVectorEnv:
         if self.single_agent and a.dim() == 1:
             a = a[:, None]
         out = self._sim.step(a.to(torch.uint8))
-        # RecordEpisodeStatistics, one set of counters per environment
-        self._ret += out.reward
-        self._len += 1
-        done = out.terminated.bool().all(dim=1) | out.truncated.bool()[:, 0]
+        # RecordEpisodeStatistics, one set of counters per environment, by ONE launch (mg_episode_stats): running
+        # return and length, the mask of the environments whose episode ended, their statistics (zero elsewhere)
+        ep_ret, ep_len, done_u8 = self._ep_ret[self._flip], self._ep_len[self._flip], self._done[self._flip]
+        self._flip ^= 1  # what the last step returned stays valid for one more step
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().mg_episode_stats(
+            self.num_envs, self.num_agents, p(out.reward), p(out.terminated), p(out.truncated), p(self._ret),
+            p(self._len), p(done_u8), p(ep_ret), p(ep_len),
+            ctypes.c_void_p(torch.cuda.current_stream(self._sim.device).cuda_stream)))
+        done = done_u8.view(torch.bool)
         infos = {}
         if not self.numpy:
-            # everything stays on the GPU and nothing here waits for it: the episode statistics of the
-            # environments that finished (zero elsewhere) and the mask that marks them are returned every step
+            # everything stays on the GPU and nothing here waits for it
             infos["_final_info"] = done
-            infos["episode_return"] = self._view(torch.where(done[:, None], self._ret, torch.zeros_like(self._ret)))
-            infos["episode_length"] = torch.where(done, self._len, torch.zeros_like(self._len))
-            self._ret.masked_fill_(done[:, None], 0.0)
-            self._len.masked_fill_(done, 0)
+            infos["episode_return"] = self._view(ep_ret)
+            infos["episode_length"] = ep_len
         elif bool(done.any()):
-            ep_ret = torch.where(done[:, None], self._ret, torch.zeros_like(self._ret))
-            ep_len = torch.where(done, self._len, torch.zeros_like(self._len))
             infos["_final_info"] = self._view_mask(done)
             infos["episode_return"] = self._view(ep_ret)
             infos["episode_length"] = ep_len.cpu().numpy() if self.numpy else ep_len
@@ -112,10 +119,9 @@ class MultiGridVectorEnv:
             for k, i in enumerate(idx):
                 final[i] = {"episode": {"r": float(r[k, 0]) if self.single_agent else r[k], "l": int(l[k])}}
             infos["final_info"] = final
-            self._ret.masked_fill_(done[:, None], 0.0)
-            self._len.masked_fill_(done, 0)
-        return (self._obs(out), self._view(out.reward), self._view(out.terminated.bool()),
-                self._view(out.truncated.bool()), infos)
+        # (the flags are bytes of 0 / 1: reinterpreted as booleans, not converted)
+        return (self._obs(out), self._view(out.reward), self._view(out.terminated.view(torch.bool)),
+                self._view(out.truncated.view(torch.bool)), infos)
 
     def _view_mask(self, done):
         return done.cpu().numpy() if self.numpy else done

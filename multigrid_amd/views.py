@@ -62,9 +62,12 @@ class BatchedRLlibView:
         """``actions`` uint8 ``[E, A]`` on the GPU.  Returns ``(obs, rewards, terminations, truncations, infos)``;
         ``terminations["__all__"][e] == all(terminations["agents"][e])`` and likewise for truncations."""
         out = self.sim.step(actions, order)
-        term, trunc = out.terminated.bool(), out.truncated.bool()
+        # the flags are bytes of 0 / 1: reinterpreted as booleans, not converted
+        term, trunc = out.terminated.view(torch.bool), out.truncated.view(torch.bool)
         terminations = {"agents": term, "__all__": term.all(dim=1)}
-        truncations = {"agents": trunc, "__all__": trunc.all(dim=1)}
+        # one truncation flag per environment, repeated for every agent (multigrid/base.py:401-402): all() of a
+        # row is its first entry
+        truncations = {"agents": trunc, "__all__": trunc[:, 0]}
         return self._obs(out), out.reward, terminations, truncations, {}
 
 

@@ -45,6 +45,8 @@ def test_bad_arguments_fail_without_a_gpu():
     assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"batch_envs" in L.mg_last_error(None)
     assert L.mg_step_shards(None, 0, None, None, None, None) == -1  # an empty shard list
     assert b"mg_step_shards" in L.mg_last_error(None)
+    assert L.mg_episode_stats(4, 2, None, None, None, None, None, None, None, None, None) == -1
+    assert b"mg_episode_stats" in L.mg_last_error(None)
 
 
 def test_product_never_imports_the_oracle():

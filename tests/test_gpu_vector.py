@@ -83,3 +83,40 @@ def test_vector_env_contract(name, agents, single, kw):
     assert finished >= n  # every environment was truncated at least once
     assert obs["image"].shape == ((n, 7, 7, 24) if single else (n, agents, 7, 7, 24))
     venv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("e,a", [(1, 1), (1000, 1), (777, 5), (4096, 8)])
+def test_episode_stats_launch_matches_the_per_field_arithmetic(e, a):
+    """mg_episode_stats against the same bookkeeping written with tensor operations (RecordEpisodeStatistics:
+    running return and length, episode over when all agents are terminated or the environment is truncated)."""
+    import ctypes
+
+    import torch
+
+    from multigrid_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(e + a)
+    ret = torch.zeros((e, a), dtype=torch.float64, device=dev)
+    length = torch.zeros((e,), dtype=torch.int64, device=dev)
+    ret_ref, len_ref = ret.clone(), length.clone()
+    done = torch.zeros((e,), dtype=torch.uint8, device=dev)
+    ep_ret = torch.zeros((e, a), dtype=torch.float64, device=dev)
+    ep_len = torch.zeros((e,), dtype=torch.int64, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for t in range(40):
+        reward = torch.rand((e, a), generator=g, device=dev, dtype=torch.float32) * (torch.rand((e, a), generator=g, device=dev) < 0.3)
+        term = (torch.rand((e, a), generator=g, device=dev) < 0.6).to(torch.uint8)
+        trunc = (torch.rand((e, 1), generator=g, device=dev) < 0.05).to(torch.uint8).expand(e, a).contiguous()
+        _lib.check(_lib.lib().mg_episode_stats(e, a, p(reward), p(term), p(trunc), p(ret), p(length), p(done), p(ep_ret),
+                                               p(ep_len), None))
+        ret_ref += reward
+        len_ref += 1
+        over = term.bool().all(dim=1) | trunc.bool()[:, 0]
+        assert torch.equal(done.bool(), over)
+        assert torch.equal(ep_ret, torch.where(over[:, None], ret_ref, torch.zeros_like(ret_ref)))
+        assert torch.equal(ep_len, torch.where(over, len_ref, torch.zeros_like(len_ref)))
+        ret_ref.masked_fill_(over[:, None], 0.0)
+        len_ref.masked_fill_(over, 0)
+        assert torch.equal(ret, ret_ref) and torch.equal(length, len_ref)
+    assert _lib.lib().mg_episode_stats(0, a, None, None, None, None, None, None, None, None, None) == -1
