@@ -56,6 +56,12 @@ class MultiGridVectorEnv:
         self._ep_len = torch.zeros((2, self.num_envs), dtype=torch.int64, device=dev)
         self._done = torch.zeros((2, self.num_envs), dtype=torch.uint8, device=dev)
         self._flip = 0
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        o = self._sim.out  # every tensor involved lives as long as this object: the argument lists are made once
+        self._stats_sets = [
+            (self._ep_ret[k], self._ep_len[k], self._done[k].view(torch.bool),
+             (self.num_envs, self.num_agents, p(o.reward), p(o.terminated), p(o.truncated), p(self._ret), p(self._len),
+              p(self._done[k]), p(self._ep_ret[k]), p(self._ep_len[k]))) for k in range(2)]
 
     # -- helpers ----------------------------------------------------------------------------------
     def _view(self, t: torch.Tensor):
@@ -95,14 +101,10 @@ class MultiGridVectorEnv:
         out = self._sim.step(a.to(torch.uint8))
         # RecordEpisodeStatistics, one set of counters per environment, by ONE launch (mg_episode_stats): running
         # return and length, the mask of the environments whose episode ended, their statistics (zero elsewhere)
-        ep_ret, ep_len, done_u8 = self._ep_ret[self._flip], self._ep_len[self._flip], self._done[self._flip]
+        ep_ret, ep_len, done, args = self._stats_sets[self._flip]
         self._flip ^= 1  # what the last step returned stays valid for one more step
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
         _lib.check(_lib.lib().mg_episode_stats(
-            self.num_envs, self.num_agents, p(out.reward), p(out.terminated), p(out.truncated), p(self._ret),
-            p(self._len), p(done_u8), p(ep_ret), p(ep_len),
-            ctypes.c_void_p(torch.cuda.current_stream(self._sim.device).cuda_stream)))
-        done = done_u8.view(torch.bool)
+            *args, ctypes.c_void_p(torch.cuda.current_stream(self._sim.device).cuda_stream)))
         infos = {}
         if not self.numpy:
             # everything stays on the GPU and nothing here waits for it
