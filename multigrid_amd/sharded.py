@@ -173,6 +173,12 @@ class StreamShardedMultiGrid:
         parts = self._each(lambda k, sh, lo, hi: sh.get_state())
         return {key: torch.cat([p[key] for p in parts]) for key in parts[0]}
 
+    def agent_rows(self):
+        """Agent rows uint8 ``[E, A, 8]`` and step counts int32 ``[E]`` of the current state (as
+        ``BatchedMultiGrid.agent_rows``), so that the batch views of ``views.py`` work over a sharded batch too."""
+        parts = self._each(lambda k, sh, lo, hi: sh.agent_rows())
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+
     def set_state(self, grid=None, agents=None, meta=None, steps=None, flags=None):
         dev = self.device
         t = lambda x: None if x is None else torch.as_tensor(x).to(device=dev)

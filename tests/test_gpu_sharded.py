@@ -150,3 +150,58 @@ def test_fused_steps_per_shard(case, e):
     assert (whole.stats().cpu() == cut.stats().cpu()).all()
     whole.close()
     cut.close()
+
+
+def test_batch_views_over_shards():
+    """The RLlib / PettingZoo batch views take a sharded batch in place of a single handle."""
+    import torch
+    from multigrid_amd.views import BatchedParallelView, BatchedRLlibView
+    spec, pool, whole, cut = make_pair("odd3", 700, 2, autoreset=0)
+    a = spec["num_agents"]
+    vw, vc = BatchedRLlibView(whole), BatchedRLlibView(cut)
+    pw, pc = BatchedParallelView(whole), BatchedParallelView(cut)
+    vw.reset()
+    vc.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    for t in range(35):
+        acts = torch.randint(0, 7, (700, a), generator=g, device="cuda:0", dtype=torch.uint8)
+        order = torch.argsort(torch.rand((700, a), generator=g, device="cuda:0"), dim=1).to(torch.uint8)
+        rw, rc = vw.step(acts, order), vc.step(acts, order)
+        torch.cuda.synchronize()
+        assert torch.equal(rw[0]["image"], rc[0]["image"]) and torch.equal(rw[1], rc[1])
+        for k in ("agents", "__all__"):
+            assert torch.equal(rw[2][k], rc[2][k]) and torch.equal(rw[3][k], rc[3][k])
+        assert torch.equal(pw.agents_mask, pc.agents_mask) and torch.equal(pw.is_done(), pc.is_done())
+    whole.close()
+    cut.close()
+
+
+def test_closed_loop_per_slice_equals_whole_batch():
+    """Observations -> policy -> actions -> step with each slice's policy and step on the slice's own stream (no
+    fork, no join: nothing outside a slice is read) ends in the state of the same loop over one handle."""
+    import torch
+    spec, pool, whole, cut = make_pair("cfg4", 1800, 2, autoreset=1, seed=3)
+    a = spec["num_agents"]
+
+    def policy(image, direction, t):
+        ahead = image[:, :, 3, 5, 0]
+        mix = image[:, :, 3, 6, 1].to(torch.int32) + image[:, :, 2, 6, 0] + direction + t
+        return torch.where(ahead == 1, 2, 3 + mix % 4).to(torch.uint8)  # forward, or pickup / drop / toggle / done
+
+    ow, oc = whole.reset(), cut.reset()
+    torch.cuda.synchronize()
+    for t in range(80):
+        whole.step(policy(ow.image, ow.direction, t))
+    for k, (sh, (lo, hi)) in enumerate(zip(cut.shards, cut.bounds)):
+        with torch.cuda.stream(cut.streams[k]):  # the whole run of slice k is queued before slice k + 1 starts
+            for t in range(80):
+                sh.step(policy(oc.image[lo:hi], oc.direction[lo:hi], t))
+    torch.cuda.synchronize()
+    for f in FIELDS:
+        assert torch.equal(getattr(ow, f), getattr(oc, f)), f
+    st_w, st_c = whole.get_state(), cut.get_state()
+    for key in st_w:
+        assert torch.equal(st_w[key], st_c[key]), key
+    assert (whole.stats().cpu() == cut.stats().cpu()).all()
+    whole.close()
+    cut.close()
