@@ -179,7 +179,8 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
  * waits for the slowest wavefront of step t.  Shards on separate streams wait only for themselves, so the
  * start and the drain of one shard's launch overlap the other's (two shards: 16 % less time per step of
  * 131072 x 8 agents on MI355X).  The caller orders each stream against the producers of its inputs and the
- * consumers of its outputs (events); nothing here synchronises.  Stops at the first shard that fails. */
+ * consumers of its outputs (events); nothing here synchronises.  Every shard is checked as mg_step checks
+ * it before the first one is launched. */
 int mg_step_shards(const MgHandle *shards, int32_t num_shards, const uint8_t *actions_dev, const uint8_t *order_dev,
                    const MgOut *out, void *const *streams);
 

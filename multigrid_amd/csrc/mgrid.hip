@@ -3504,8 +3504,11 @@ int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev,
     return MG_OK;
 }
 
-int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out, void *stream) {
-    if (!h) return MG_EINVAL;
+}  // extern "C"
+
+namespace {
+// what mg_step checks before it launches anything
+int step_ready(MgHandle h, const uint8_t *actions_dev, const MgOut *out) {
     if (!actions_dev) return fail(h, MG_EINVAL, "mg_step: actions_dev is null");
     if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_step: onehot_dev must be 8-byte aligned");
     if (h->kp.comp() && out && out->onehot_dev)
@@ -3513,6 +3516,16 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_step: call mg_reset (or mg_set_state) first");
     if (h->cfg.autoreset != MG_AUTORESET_NONE && h->num_layouts < 1)
         return fail(h, MG_ESTATE, "mg_step: autoreset needs uploaded layouts");
+    return MG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, const MgOut *out, void *stream) {
+    if (!h) return MG_EINVAL;
+    const int ready = step_ready(h, actions_dev, out);
+    if (ready != MG_OK) return ready;
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
     kp.actions = actions_dev;
@@ -3590,6 +3603,12 @@ int mg_step_shards(const MgHandle *shards, int32_t num_shards, const uint8_t *ac
                         c.env_id_offset, static_cast<long long>(c0.env_id_offset + first));
         for (int32_t j = 0; j < k; ++j)
             if (shards[j] == h) return fail(shards[0], MG_EINVAL, "mg_step_shards: shard %d is listed twice", k);
+        // no shard steps unless all of them can (the slices' output pointers share the alignment that matters)
+        const int ready = step_ready(h, actions_dev, out);
+        if (ready != MG_OK) {
+            if (k > 0) fail(shards[0], ready, "mg_step_shards: shard %d: %s", k, h->err.c_str());
+            return ready;
+        }
         first += c.num_envs;
     }
     const size_t a = static_cast<size_t>(c0.num_agents), img = 3u * c0.view_size * c0.view_size;

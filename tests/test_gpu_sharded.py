@@ -121,6 +121,15 @@ def test_shard_list_is_checked():
     assert _lib.lib().mg_step_shards(None, 0, None, None, None, None) == -1
     torch.cuda.synchronize()
     env.close()
+    # a slice that cannot step keeps every slice from stepping
+    env = StreamShardedMultiGrid(spec, 256, shards=2, device=0)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    env.shards[0].reset()
+    with pytest.raises(_lib.MgError, match="shard 1"):
+        env.step(acts)
+    torch.cuda.synchronize()
+    assert int(env.shards[0].stats()[5]) == 0
+    env.close()
 
 
 @pytest.mark.parametrize("case,e", [("cfg5", 1500), ("cfg3", 2100)])
