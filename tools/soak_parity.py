@@ -1,18 +1,24 @@
 """Long randomized parity run against the C oracle (test infrastructure, not a product path): many steps of mid-sized
 batches with same-step auto-reset, biased action mixes that make pickups, drops, door toggles and hook events frequent.
-    python tools/soak_parity.py [seconds per case]"""
+    python tools/soak_parity.py [seconds per case]        (SOAK_SHARDS=2: through StreamShardedMultiGrid)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import test_gpu_batch as tb
 
+SHARDS = int(os.environ.get("SOAK_SHARDS", "1"))
 CASES = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_nooverlap", "crowd8_bup", "crowd6_lh", "crowd8_rbd", "odd3", "odd5", "single"]
 MIXES = [None, [1, 1, 3, 2, 2, 3, 1], [1, 1, 2, 4, 1, 4, 0]]  # weights over left right forward pickup drop toggle done
 
 
 def run(case, seconds, e=3000, seed=0):
     spec, pool, env, ora = tb.make(case, e, autoreset=2)
+    if SHARDS > 1:  # the same batch as slices on streams of their own (mg_step_shards)
+        from multigrid_amd.sharded import StreamShardedMultiGrid
+        env.close()
+        env = StreamShardedMultiGrid(spec, e, shards=SHARDS, device=0, autoreset=2)
+        env.upload_layouts(pool[0], pool[1], pool[2])
     a, n_l = spec["num_agents"], len(pool[0])
     rng = np.random.default_rng(seed)
     ids_all = np.arange(e)
