@@ -241,6 +241,13 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
 #define MG_NUM_STATS 8
 int mg_stats(MgHandle h, int64_t *stats_dev, void *stream);
 
+/* Replaces PettingZooWrapper.agents (multigrid/pettingzoo/__init__.py:48-52) and MultiGridEnv.is_done
+ * (multigrid/base.py:587-596) for every environment, by one launch: done_dev uint8[E] = the step count has reached
+ * max_steps or every agent is terminated (the environment's own flags, agent_states.terminated, not the returned
+ * dict); mask_dev uint8[E][A] = agent k is listed in `agents`, i.e. it is not terminated and the environment is not
+ * done.  Either pointer may be NULL. */
+int mg_agents_mask(MgHandle h, uint8_t *mask_dev, uint8_t *done_dev, void *stream);
+
 /* Per-environment episode statistics of a vector of environments after a step with MG_AUTORESET_SAME_STEP, by one
  * launch: replaces gym.wrappers.RecordEpisodeStatistics around every environment of the reference's SyncVectorEnv
  * (multigrid/scripts/train_ppo_cleanrl.py:173,366) and the `final_info` entries its training loop reads

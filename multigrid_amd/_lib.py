@@ -25,7 +25,7 @@ ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
            "mg_set_reward_schemes",
            "mg_reset", "mg_step", "mg_step_shards", "mg_step_n", "mg_gen_obs", "mg_gen_obs_of_state", "mg_get_state", "mg_set_state",
-           "mg_stats", "mg_episode_stats")
+           "mg_stats", "mg_episode_stats", "mg_agents_mask")
 
 
 class MgConfig(ctypes.Structure):
@@ -117,6 +117,8 @@ def lib() -> ctypes.CDLL:
         L.mg_get_state.argtypes = [vp] * 7
         L.mg_set_state.argtypes = [vp] * 7
         L.mg_stats.argtypes = [vp, vp, vp]
+        if hasattr(L, "mg_agents_mask"):
+            L.mg_agents_mask.argtypes = [vp, vp, vp, vp]
         if hasattr(L, "mg_episode_stats"):
             L.mg_episode_stats.argtypes = [i32, i32] + [vp] * 9
         for name in EXPORTS:

@@ -238,6 +238,17 @@ class BatchedMultiGrid:
         check(_lib.lib().mg_get_state(self._h, None, _ptr(agents), None, _ptr(steps), None, self._stream()), self._h)
         return agents, steps
 
+    def agents_mask(self, mask: Optional[torch.Tensor] = None, done: Optional[torch.Tensor] = None):
+        """``PettingZooWrapper.agents`` as a bool ``[E, A]`` tensor and ``MultiGridEnv.is_done`` as a bool ``[E]``
+        tensor for every environment, by one launch (``mg_agents_mask``); ``mask`` / ``done``: uint8 tensors to write
+        into instead of fresh ones."""
+        if mask is None:
+            mask = torch.empty((self.E, self.A), dtype=torch.uint8, device=self.device)
+        if done is None:
+            done = torch.empty((self.E,), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mg_agents_mask(self._h, _ptr(mask), _ptr(done), self._stream()), self._h)
+        return mask.view(torch.bool), done.view(torch.bool)
+
     def set_state(self, grid=None, agents=None, meta=None, steps=None, flags=None):
         e = self.E
         g = None if grid is None else self._dev_u8(grid, (e, self.W, self.H, 3))

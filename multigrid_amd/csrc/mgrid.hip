@@ -2646,6 +2646,21 @@ __global__ void mg_get_state_kernel(KParams p, uint8_t *grid, uint8_t *agents, u
     }
 }
 
+// PettingZooWrapper.agents (multigrid/pettingzoo/__init__.py:48-52) and MultiGridEnv.is_done
+// (multigrid/base.py:587-596) of every environment, one thread per environment, straight from the header blocks.
+__global__ void mg_agents_mask_kernel(KParams p, uint8_t *mask, uint8_t *done) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    const uint8_t *h = p.hdr + static_cast<size_t>(e) * p.HS;
+    const int a = p.A();
+    bool all_term = true;
+    for (int k = 0; k < a; ++k) all_term = all_term && h[H_ROWS + 8 * k + 3] != 0;
+    const bool over = *reinterpret_cast<const int32_t *>(h + H_STEP) >= p.max_steps || all_term;
+    if (done) done[e] = over ? 1 : 0;
+    if (mask)
+        for (int k = 0; k < a; ++k) mask[static_cast<size_t>(e) * a + k] = (!over && h[H_ROWS + 8 * k + 3] == 0) ? 1 : 0;
+}
+
 __global__ void mg_stats_kernel(const int64_t *shards, int64_t *out, int64_t launches) {
     const int k = threadIdx.x;
     if (k >= MG_NUM_STATS) return;
@@ -3733,6 +3748,16 @@ int mg_dbg_buffer(MgHandle h, void *buf_dev, int *num_tiles) {
     return MG_OK;
 }
 #endif
+
+int mg_agents_mask(MgHandle h, uint8_t *mask_dev, uint8_t *done_dev, void *stream) {
+    if (!h) return MG_EINVAL;
+    if (!h->reset_done) return fail(h, MG_ESTATE, "mg_agents_mask: call mg_reset (or mg_set_state) first");
+    MG_HIP(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(mg_agents_mask_kernel, dim3((h->kp.E + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h->kp, mask_dev, done_dev);
+    MG_HIP(h, hipGetLastError());
+    return MG_OK;
+}
 
 int mg_episode_stats(int32_t num_envs, int32_t num_agents, const float *reward_dev, const uint8_t *terminated_dev,
                      const uint8_t *truncated_dev, double *return_acc_dev, int64_t *length_acc_dev, uint8_t *done_dev,

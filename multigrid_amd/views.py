@@ -90,12 +90,16 @@ class BatchedParallelView:
 
     def is_done(self) -> torch.Tensor:
         """``MultiGridEnv.is_done`` per environment (multigrid/base.py:587-596), bool ``[E]``."""
+        if hasattr(self.sim, "agents_mask"):  # one launch
+            return self.sim.agents_mask()[1]
         rows, steps = self.sim.agent_rows()
         return (steps >= self.max_steps) | rows[:, :, 3].bool().all(dim=1)
 
     @property
     def agents_mask(self) -> torch.Tensor:
         """bool ``[E, A]``: agent k is in ``PettingZooWrapper(env_e).agents`` (pettingzoo/__init__.py:48-52)."""
+        if hasattr(self.sim, "agents_mask"):  # one launch
+            return self.sim.agents_mask()[0]
         rows, steps = self.sim.agent_rows()
         alive = ~rows[:, :, 3].bool()
         done = (steps >= self.max_steps) | ~alive.any(dim=1)
