@@ -90,6 +90,12 @@ class StreamShardedMultiGrid:
             with torch.cuda.stream(self.streams[k]):
                 res.append(fn(k, sh, lo, hi))
         self.join()
+        # tensors the slices allocated on their streams are read on the current stream from here on
+        cur = torch.cuda.current_stream(self.device)
+        for r in res:
+            for t in (r.values() if isinstance(r, dict) else r if isinstance(r, (tuple, list)) else (r,)):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
         return res
 
     # -- API (as BatchedMultiGrid) -------------------------------------------------------------
@@ -162,6 +168,12 @@ class StreamShardedMultiGrid:
                 res.append(sh.step_n(acts[k], ords[k], out=None if outs is None else outs[k]))
         if join:
             self.join()
+            if outs is None:  # allocated on the slices' streams, read on the current one from here on
+                cur = torch.cuda.current_stream(self.device)
+                for o in res:
+                    for t in (o.image, o.direction, o.reward, o.terminated, o.truncated, o.onehot):
+                        if t is not None:
+                            t.record_stream(cur)
         return res
 
     def gen_obs(self) -> StepOutput:

@@ -27,7 +27,8 @@ def run(cfg_id, shards, steps=1504, warm=1008, graph=False, num_envs=0):
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     for s in range(shards):
-        h = BatchedMultiGrid(spec, es, device=dev, autoreset=_lib.AUTORESET_SAME_STEP, env_id_offset=s * es, seed=1234)
+        h = BatchedMultiGrid(spec, es, device=dev, autoreset=_lib.AUTORESET_SAME_STEP, env_id_offset=s * es, seed=1234,
+                             batch_envs=num_envs if os.environ.get("EXP_BATCH_HINT", "1") == "1" else 0)
         h.upload_layouts(*pool)
         h.reset()
         h.set_state(steps=torch.randint(0, spec["max_steps"], (es,), generator=g, device=dev, dtype=torch.int32))
