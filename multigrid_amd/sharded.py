@@ -25,21 +25,27 @@ from .batched import BatchedMultiGrid, StepOutput, _ptr
 ALIGN_ENVS = 64  # slices start at a multiple of this: their parts of the output arrays stay 16-byte aligned
 
 
+def slice_bounds(num_envs: int, shards: int):
+    """``[(first, end), ...]``: at most ``shards`` consecutive slices of ``num_envs`` environments, equal in size up
+    to rounding to ``ALIGN_ENVS`` (the last one takes what is left; fewer slices when the batch is small)."""
+    if num_envs < 1 or shards < 1:
+        raise ValueError("num_envs and shards must be positive")
+    per = -(-num_envs // shards)
+    per = -(-per // ALIGN_ENVS) * ALIGN_ENVS
+    return [(lo, min(lo + per, num_envs)) for lo in range(0, num_envs, per)]
+
+
 class StreamShardedMultiGrid:
     def __init__(self, spec: dict, num_envs: int, shards: int = 2, device: int | str | torch.device = 0,
                  autoreset: int = _lib.AUTORESET_NONE, env_id_offset: int = 0, seed: int = 0,
                  one_hot: bool = False, compact_image: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamShardedMultiGrid needs a ROCm GPU (no CPU fallback)")
-        if shards < 1:
-            raise ValueError("shards must be positive")
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         self.device, self.spec = dev, dict(spec)
         self.E, self.A, self.V = int(num_envs), int(spec["num_agents"]), int(spec["view_size"])
         self.W, self.H = int(spec["width"]), int(spec["height"])
-        per = -(-self.E // shards)
-        per = -(-per // ALIGN_ENVS) * ALIGN_ENVS
-        self.bounds = [(lo, min(lo + per, self.E)) for lo in range(0, self.E, per)]
+        self.bounds = slice_bounds(self.E, shards)
         e, a, v = self.E, self.A, self.V
         self.out = StepOutput(
             image=torch.zeros((e, a, v, v, 3), dtype=torch.uint8, device=dev) if compact_image or not one_hot else None,
