@@ -214,3 +214,25 @@ def test_closed_loop_per_slice_equals_whole_batch():
     assert (whole.stats().cpu() == cut.stats().cpu()).all()
     whole.close()
     cut.close()
+
+
+@pytest.mark.parametrize("case,e,mode", [("cfg5", 900, 2), ("cfg3", 1300, 2), ("odd3", 640, 0)])
+def test_shards_with_one_hot_images_and_other_reset_modes(case, e, mode):
+    """One-hot images written by the slices' launches (every slice's part of the array starts 8-byte aligned), with
+    next-step auto-reset and without auto-reset, injected agent orders."""
+    import torch
+    spec, pool, whole, cut = make_pair(case, e, 3, autoreset=mode, seed=1, one_hot=True)
+    a = spec["num_agents"]
+    ow, oc = whole.reset(), cut.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(ow.onehot, oc.onehot)
+    g = torch.Generator(device="cuda:0").manual_seed(6)
+    for t in range(45):
+        acts = torch.randint(0, 7, (e, a), generator=g, device="cuda:0", dtype=torch.uint8)
+        order = torch.argsort(torch.rand((e, a), generator=g, device="cuda:0"), dim=1).to(torch.uint8)
+        w, c = whole.step(acts, order), cut.step(acts, order)
+        torch.cuda.synchronize()
+        for f in FIELDS + ("onehot",):
+            assert torch.equal(getattr(w, f), getattr(c, f)), f"{case} step {t} {f}"
+    whole.close()
+    cut.close()
