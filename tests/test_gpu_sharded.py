@@ -236,3 +236,36 @@ def test_shards_with_one_hot_images_and_other_reset_modes(case, e, mode):
             assert torch.equal(getattr(w, f), getattr(c, f)), f"{case} step {t} {f}"
     whole.close()
     cut.close()
+
+
+def test_shards_of_competitive_environments():
+    """CompetativeRedBlueDoorEnvV3 (death match, per-agent reward schemes set on every slice's handle) as shards."""
+    import torch
+    from multigrid_amd.batched import BatchedMultiGrid
+    from multigrid_amd.sharded import StreamShardedMultiGrid
+    spec, gen = envs.make_spec("MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2-Death-Match", max_steps=40)
+    pool = layouts.make_pool(gen, 32, seed0=5)
+    e, a = 1200, spec["num_agents"]
+    whole = BatchedMultiGrid(spec, e, device=0, autoreset=1)
+    cut = StreamShardedMultiGrid(spec, e, shards=2, device=0, autoreset=1)
+    for x in (whole, cut):
+        x.upload_layouts(pool[0], pool[1], pool[2])
+        x.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(12)
+    paid = 0
+    for t in range(120):
+        # forward, pickup and toggle often: keys, balls, doors and opponents are reached
+        acts = torch.multinomial(torch.tensor([0.1, 0.1, 0.3, 0.2, 0.05, 0.23, 0.02], device="cuda:0"), e * a,
+                                 replacement=True, generator=g).view(e, a).to(torch.uint8)
+        order = torch.argsort(torch.rand((e, a), generator=g, device="cuda:0"), dim=1).to(torch.uint8)
+        w, c = whole.step(acts, order), cut.step(acts, order)
+        torch.cuda.synchronize()
+        for f in FIELDS:
+            assert torch.equal(getattr(w, f), getattr(c, f)), f"step {t} {f}"
+        paid += int((w.reward != 0).sum())
+    assert paid > 0
+    st_w, st_c = whole.get_state(), cut.get_state()
+    for k in st_w:
+        assert torch.equal(st_w[k], st_c[k]), k
+    whole.close()
+    cut.close()
