@@ -1888,6 +1888,11 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
 #ifdef MGRID_EXPERIMENT
     unsigned long long tstart = 0;
     MG_TICK(tstart);
+    // Staggered start (diagnostic): MGRID_DBG bit 6 delays the tiles whose index has bit ((dbg >> 16) & 31) set by
+    // ((dbg >> 8) & 255) sleeps of 127 x 64 clocks, so that the wavefronts sharing a SIMD are not all in the same
+    // phase of the step at the same time.
+    if ((p.dbg & 64) && ((blockIdx.x >> ((p.dbg >> 16) & 31)) & 1))
+        for (int i = 0, n = (p.dbg >> 8) & 255; i < n; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     constexpr bool small = SMALLA;  // A <= 8, chosen by the host
     // which environments take part (a masked reset skips some)
