@@ -86,7 +86,7 @@ def test_vector_env_contract(name, agents, single, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("e,a", [(1, 1), (1000, 1), (777, 5), (4096, 8)])
+@pytest.mark.parametrize("e,a", [(1, 1), (1000, 1), (777, 5), (4096, 8), (3, 64), (5, 200), (2, 256)])
 def test_episode_stats_launch_matches_the_per_field_arithmetic(e, a):
     """mg_episode_stats against the same bookkeeping written with tensor operations (RecordEpisodeStatistics:
     running return and length, episode over when all agents are terminated or the environment is truncated)."""
@@ -120,3 +120,5 @@ def test_episode_stats_launch_matches_the_per_field_arithmetic(e, a):
         len_ref.masked_fill_(over, 0)
         assert torch.equal(ret, ret_ref) and torch.equal(length, len_ref)
     assert _lib.lib().mg_episode_stats(0, a, None, None, None, None, None, None, None, None, None) == -1
+    assert _lib.lib().mg_episode_stats(e, 257, p(reward), p(term), p(trunc), p(ret), p(length), p(done), p(ep_ret),
+                                       p(ep_len), None) == -1

@@ -130,3 +130,32 @@ def test_views_and_vector_env_never_wait_for_the_gpu():
     assert enqueue < 0.7 * total, (enqueue, total)
     venv.close()
     sim.close()
+
+
+@pytest.mark.gpu
+def test_agents_mask_launch_matches_the_agent_rows():
+    """mg_agents_mask against the same rule written over the agent rows and step counts, for 1, 7 and 64 agents, with
+    agents terminated one by one (success_termination_mode "all") and with truncation."""
+    import torch
+
+    from multigrid_amd.batched import BatchedMultiGrid
+    for name, agents, e in (("MultiGrid-Empty-Random-6x6-v0", 7, 500), ("MultiGrid-Empty-16x16-v0", 64, 70),
+                            ("MultiGrid-BlockedUnlockPickup-v0", 1, 300)):
+        spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=3, max_steps=25, success_termination_mode="all")
+        pool = layouts.make_pool(gen, 8, seed0=2)
+        sim = BatchedMultiGrid(spec, e, device=0)
+        sim.upload_layouts(pool[0], pool[1], pool[2])
+        sim.reset()
+        g = torch.Generator(device="cuda:0").manual_seed(agents)
+        seen = set()
+        for t in range(27):
+            mask, done = sim.agents_mask()
+            rows, steps = sim.agent_rows()
+            alive = rows[:, :, 3] == 0
+            over = (steps >= spec["max_steps"]) | ~alive.any(dim=1)
+            assert torch.equal(done, over) and torch.equal(mask, alive & ~over[:, None]), (name, t)
+            seen.add((bool(over.any()), bool(over.all()), bool((~alive).any())))
+            sim.step(torch.full((e, agents), 2, dtype=torch.uint8, device="cuda:0") if t % 3 else
+                     torch.randint(0, 3, (e, agents), generator=g, device="cuda:0", dtype=torch.uint8))
+        assert (True, True, False) in seen or (True, True, True) in seen  # everything truncated in the end
+        sim.close()
