@@ -56,6 +56,7 @@ class MultiGridVectorEnv:
         self._ep_len = torch.zeros((2, self.num_envs), dtype=torch.int64, device=dev)
         self._done = torch.zeros((2, self.num_envs), dtype=torch.uint8, device=dev)
         self._flip = 0
+        self._mg_episode_stats = _lib.lib().mg_episode_stats
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         o = self._sim.out  # every tensor involved lives as long as this object: the argument lists are made once
         self._stats_sets = [
@@ -103,8 +104,9 @@ class MultiGridVectorEnv:
         # return and length, the mask of the environments whose episode ended, their statistics (zero elsewhere)
         ep_ret, ep_len, done, args = self._stats_sets[self._flip]
         self._flip ^= 1  # what the last step returned stays valid for one more step
-        _lib.check(_lib.lib().mg_episode_stats(
-            *args, ctypes.c_void_p(torch.cuda.current_stream(self._sim.device).cuda_stream)))
+        rc = self._mg_episode_stats(*args, self._sim._stream())
+        if rc != 0:
+            _lib.check(rc)
         infos = {}
         if not self.numpy:
             # everything stays on the GPU and nothing here waits for it
