@@ -174,7 +174,8 @@ int mg_step(MgHandle h, const uint8_t *actions_dev, const uint8_t *order_dev, co
  * WHOLE batch's arrays, laid out as for mg_step, and every shard reads and writes its own slice of them.  The
  * results are those of one handle holding the whole batch (MultiGridEnv.step, multigrid/base.py:364-408, per
  * environment; the reference runs groups of environments side by side as rollout workers,
- * multigrid/utils/training_utilis.py:273 `num_rollout_workers`, and as a vector of environments, scripts/train_ppo_cleanrl.py:366).
+ * multigrid/utils/training_utilis.py:273 `num_rollout_workers`, and as a vector of environments,
+ * multigrid/scripts/train_ppo_cleanrl.py:366).
  * Why: environments are independent, but launches on one stream are not - step t + 1 of every environment
  * waits for the slowest wavefront of step t.  Shards on separate streams wait only for themselves, so the
  * start and the drain of one shard's launch overlap the other's (two shards: 16 % less time per step of
