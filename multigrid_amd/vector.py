@@ -13,6 +13,8 @@ This is the contract of ``gymnasium.vector.SyncVectorEnv`` as the reference uses
   are available without leaving the device as ``infos["episode_return"]`` / ``["episode_length"]``.
   With ``numpy=False`` (the default) ``step`` never waits for the GPU: it returns the mask and those two
   tensors every step (zeros where no episode ended) and leaves out the per-environment Python objects.
+  Those three tensors are written in place, two sets used in turn: what one ``step`` returned is overwritten by
+  the second ``step`` after it (observations, rewards and flags already by the next one), so copy what must last.
 
 Every array is a PyTorch-ROCm tensor written in place by the HIP kernels (``numpy=True`` converts
 at the boundary like ``SyncVectorEnv`` does).  With ``single_agent=True`` (one agent per
