@@ -53,11 +53,24 @@ def algorithmic_bytes_per_env_step(spec, one_hot=False, steps_per_launch=1) -> f
     return (9 + img) * a + (2 * (8 * a + 8) + 3 * w * h + 3 * a) / steps_per_launch
 
 
-def measured_traffic(name, num_envs):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic*.json), when one
-    matches this workload; the counters cannot be read from inside this process."""
+def measured_traffic(name, num_envs, stream_shards=1):
+    """HBM bytes per whole-batch step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic*.json: one
+    launch; profiles/*_stream_shards.json: the launches of all slices), when one matches this workload; the counters
+    cannot be read from inside this process.  The latest round's file wins."""
     import glob
     best = None
+    if stream_shards > 1:
+        cid = next((c for c, v in CONFIGS.items() if v[0] == name), None)
+        tag = f"cfg{cid}_{num_envs}_s{stream_shards}"
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_stream_shards.json"))):
+            try:
+                d = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            for rec in (d if isinstance(d, list) else d.get("workloads", [])):
+                if rec.get("workload") == tag and rec.get("hbm_bytes_per_launch"):
+                    best = rec["hbm_bytes_per_launch"] * stream_shards  # one launch per slice and step
+        return best
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json"))):
         try:
             d = json.load(open(path))
@@ -70,6 +83,31 @@ def measured_traffic(name, num_envs):
             if name in w and f"{num_envs} envs" in w and "overlap" not in w and "one-hot" not in w:
                 best = rec.get("hbm_bytes_per_launch")
     return best
+
+
+def fraction_fields(obj, path=""):
+    """Every (path, value) of a bench line whose key says it is a fraction of something."""
+    out = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            here = f"{path}.{k}" if path else k
+            if isinstance(v, (dict, list)):
+                out += fraction_fields(v, here)
+            elif "frac" in k and isinstance(v, (int, float)):
+                out.append((here, float(v)))
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            out += fraction_fields(v, f"{path}[{i}]")
+    return out
+
+
+def check_fractions(line):
+    """A field named `*frac*` is a part of a whole: none may exceed 1 (a time comparison belongs under another
+    name).  Raises with the offending paths."""
+    bad = [(k, v) for k, v in fraction_fields(line) if not (0.0 <= v <= 1.0)]
+    if bad:
+        raise ValueError(f"bench line carries fractions outside [0, 1]: {bad}")
+    return line
 
 
 # Rehearsal of the multi-rank path on a box with ONE GPU (MGRID_BENCH_REHEARSE=1): every rank uses GPU 0 and the
@@ -95,7 +133,7 @@ def all_reduce_(t, op):
 
 
 def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one_hot=False, repeats=1,
-            steps_per_launch=1, stream_shards=1, **override):
+            steps_per_launch=1, stream_shards=1, collective=None, **override):
     """Times `repeats` runs of `steps` step launches each (every run bracketed by a barrier and a device
     synchronisation on both sides, maximum over ranks) and returns the median run.  With `stream_shards` S > 1 the
     rank's batch is held as S slices that step on streams of their own without waiting for each other
@@ -109,6 +147,8 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **dict(kw, **override))
     dev = torch.device("cuda", local_device_index())
     torch.cuda.set_device(dev)
+    if collective is None:  # the statistics all-reduce runs whenever a process group holds more than this rank
+        collective = world > 1
     S = max(1, stream_shards)
     if S > 1:
         from multigrid_amd.sharded import StreamShardedMultiGrid
@@ -117,8 +157,13 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     else:
         env = BatchedMultiGrid(spec, num_envs, device=dev, autoreset=_lib.AUTORESET_SAME_STEP,
                                env_id_offset=rank * num_envs, seed=1234, one_hot=one_hot, compact_image=not one_hot)
-    grids, ags, metas, _ = layouts.make_pool(gen, args.layouts, seed0=0)
-    env.upload_layouts(grids, ags, metas)
+    if args.pool == "device":
+        # the pool drawn by the library on the GPU (mg_generate_layouts): layout l depends on (seed, l) only, so
+        # every rank holds the same pool without 2-6 s of host generators per rank
+        env.generate_layouts(gen, args.layouts, seed=0)
+    else:
+        grids, ags, metas, _ = layouts.make_pool(gen, args.layouts, seed0=0)
+        env.upload_layouts(grids, ags, metas)
     env.reset()
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -143,6 +188,8 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
             acts_k = [[actions[h * T:(h + 1) * T, lo:hi].contiguous() for h in range(2)] for lo, hi in env.bounds]
         else:
             outn = rollout_buffers(num_envs)
+    if S > 1:
+        env.fork()  # the slices' streams start after everything built above (actions, their per-slice copies)
 
     shard_graphs = []
 
@@ -177,6 +224,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
         run(extra_warmup, warmup)
     graphed = None
     if graph and S > 1:
+        env.fork()
         torch.cuda.synchronize(dev)
         for k, (sh, (lo, hi)) in enumerate(zip(env.shards, env.bounds)):
             gr = torch.cuda.CUDAGraph()
@@ -199,7 +247,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     walls, gpus = [], []
     for rep in range(repeats):
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         on = env.streams if S > 1 else [torch.cuda.current_stream(dev)]  # the streams the kernels are launched on
@@ -219,7 +267,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - wall0
         gpu_s = max(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / 1e3
-        if world > 1:
+        if collective:
             torch.distributed.barrier()
             t = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
             all_reduce_(t, torch.distributed.ReduceOp.MAX)
@@ -229,7 +277,7 @@ def gpu_leg(args, cfg_id, num_envs, rank, world, steps, warmup, graph=False, one
     mid = sorted(range(repeats), key=lambda i: walls[i])[repeats // 2]
     stats = env.stats()
     check = torch.tensor([1, steps, int(stats[5])], dtype=torch.int64, device=dev)
-    if world > 1:  # the path's only collective: 64 + 24 bytes over RCCL, off the step path
+    if collective:  # the path's only collective: 64 + 24 bytes over RCCL, off the step path
         from multigrid_amd import distributed
         if REHEARSE:
             stats = distributed.allreduce_stats(stats.cpu())
@@ -297,24 +345,33 @@ def latency_one_env(args):
 
 
 def memory_rates(dev):
-    """What this GPU's memory system gives plain streaming kernels: a device-to-device copy (bytes read +
-    bytes written per second) and a fill (bytes written per second), 1 GiB each, far beyond the caches."""
+    """What this GPU's memory system gives plain streaming kernels (tools/membench/copy_rate.hip: 16 bytes per lane,
+    grid-stride): a device-to-device copy (bytes read + bytes written per second) and a fill (bytes written per
+    second), 1 GiB each, far beyond the caches.  The best of a few launch shapes is reported."""
+    import ctypes
+
     import torch
+    path = os.path.join(ROOT, "tools", "membench", "libmembench.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    mb = ctypes.CDLL(path)
+    mb.mb_stream_ms.restype = ctypes.c_float
+    mb.mb_stream_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     n = 1 << 30
     a = torch.empty(n, dtype=torch.uint8, device=dev)
     b = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     out = {}
-    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * n), ("fill", lambda: a.fill_(1), n)):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        out[name] = moved * 10 / (e0.elapsed_time(e1) / 1e3) / 1e9
+    for name, src, moved in (("copy", a, 2 * n), ("fill", None, n)):
+        best = 0.0
+        for blocks in (2048, 8192, 32768):
+            ms = mb.mb_stream_ms(None if src is None else ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                 n, 10, blocks, st)
+            if ms <= 0:
+                raise RuntimeError("the streaming yardstick kernel failed")
+            best = max(best, moved * 10 / (ms / 1e3) / 1e9)
+        out[name] = best
     return out
 
 
@@ -434,6 +491,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="allow_agent_overlap=False (agents block each other)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs")
+    ap.add_argument("--pool", choices=["auto", "host", "device"], default="auto",
+                    help="layout pool: host generators (bit-identical to the reference's layouts) or mg_generate_layouts "
+                         "on the GPU (same distribution, drawn in milliseconds); auto = host for one rank, device for several")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="with --gpus 1: join an RCCL process group of ONE rank and run the barriers and the statistics "
+                         "all-reduce on GPU tensors through it (executes the multi-GPU code path on one GPU)")
     ap.add_argument("--selftest-gloo", action="store_true",
                     help="exercise the multi-process launcher and the collectives on the CPU (gloo); no GPU, no kernel")
     return ap.parse_args(argv)
@@ -451,6 +514,9 @@ def spawn_ranks(args, argv) -> int:
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                        LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            # RCCL's intra-node transports open the peers' buffers through HIP IPC handles; the hosts this runs on
+            # support the dmabuf form only, and without this setting hipIpcGetMemHandle fails with "invalid
+            # argument" at the first collective.  Kept if the caller's environment already says something else.
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                           stdout=out0 if r == 0 else subprocess.DEVNULL))
@@ -515,12 +581,23 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
-    if world > 1:
+    backend = None
+    if world > 1 or args.force_process_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.selftest_gloo or REHEARSE:
+        if world == 1:  # a group of one rank: the same calls a multi-GPU run makes, on the one GPU there is
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("LOCAL_RANK", "0")
+        backend = "gloo" if (args.selftest_gloo or REHEARSE) else "nccl"
+        if backend == "gloo":
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    if args.pool == "auto":
+        args.pool = "device" if world > 1 else "host"
     if args.selftest_gloo:
         rc = selftest_gloo(args, rank, world)
         if world > 1:
@@ -533,15 +610,17 @@ def main(argv=None):
     T = max(1, args.fused)
     S = max(1, args.stream_shards)
     r = gpu_leg(args, args.config, num_envs, rank, world, args.steps, args.warmup, graph=args.graph, repeats=repeats,
-                steps_per_launch=T, stream_shards=S, **({"allow_agent_overlap": False} if args.no_overlap else {}))
+                steps_per_launch=T, stream_shards=S, collective=backend is not None,
+                **({"allow_agent_overlap": False} if args.no_overlap else {}))
     spec = r["spec"]
     total_agent_steps = world * num_envs * agents * args.steps
     value = total_agent_steps / r["wall"]
     launch_s = r["gpu_s"] / (args.steps / T)
     bytes_step = algorithmic_bytes_per_env_step(spec, steps_per_launch=T)
     achieved = num_envs * bytes_step * T / launch_s / 1e9
-    traffic = measured_traffic(name, num_envs) if T == 1 else None
+    traffic = measured_traffic(name, num_envs, S) if T == 1 else None
     ranks_seen, steps_sum, launches_sum = r["check"]
+    wall_step_s = r["wall"] / args.steps
 
     line = {
         "metric": "agent_steps_per_sec", "value": value, "unit": "agent-steps/s",
@@ -557,14 +636,22 @@ def main(argv=None):
                    "baseline_config": args.config, "envs_per_gpu": num_envs, "agents": agents,
                    "grid": [spec["width"], spec["height"]], "steps_per_launch": T, "stream_shards": S,
                    "extra_warmup_steps": r["extra_warmup"],
+                   "layout_pool": "mg_generate_layouts on the GPU" if args.pool == "device" else "host generators",
                    "launch": "hip_graph" if args.graph else "eager", "parallelism": f"env-shard x{world}"},
-        "rccl_ranks": (None if REHEARSE else torch.distributed.get_world_size()) if world > 1 else 1,
+        "backend": backend,
+        "rccl_ranks": (torch.distributed.get_world_size() if backend == "nccl" else None) if backend else 1,
         "collective_check": {"ranks_seen": ranks_seen, "steps_sum": steps_sum, "launches_sum": launches_sum,
                              "ok": ranks_seen == world and steps_sum == world * args.steps},
+        # `frac` is priced at the kernel's launch duration, measured by HIP events on the launch stream(s) (what
+        # rocprofv3 shows per kernel); `frac_at_ms_per_step` prices the same bytes at the wall clock `ms_per_step` is
+        # taken from (host issue, barriers and synchronisation included), so that the two clocks of this line are
+        # both on it, by name
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE from profiles/",
-                     "frac_counter_bytes": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "clock": "HIP events on the launch stream",
+                     "frac_at_ms_per_step": num_envs * bytes_step / wall_step_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic_unit": "bytes per whole-batch step, 2 x FETCH_SIZE + WRITE_SIZE from profiles/",
+                     "frac_counter_bytes": (traffic / (launch_s / T) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "kernel": ("mg_tile_kernel" if T == 1 else "mg_tile_kernel (multi-step variant)") +
                                (f", {S} launches side by side on {S} streams per step: bytes of all of them over the "
                                 f"time of a whole-batch step" if S > 1 else ""),
@@ -581,7 +668,9 @@ def main(argv=None):
         rates = memory_rates(torch.device("cuda", local_device_index()))
         line["roofline"]["measured_copy_GBs"] = rates["copy"]
         line["roofline"]["measured_fill_GBs"] = rates["fill"]
-        line["roofline"]["frac_of_measured_copy"] = achieved / rates["copy"]
+        # (a time comparison, not a part of a whole: the step re-reads cached state, a 1 GiB copy cannot)
+        line["roofline"]["achieved_over_measured_copy"] = achieved / rates["copy"]
+        line["roofline"]["measured_with"] = "tools/membench/copy_rate.hip: 16 B per lane, 1 GiB, best of 3 launch shapes"
         extra = []
 
         def add(cid, e2, label="", n_steps=400, n_warm=50, one_hot=False, **kw):
@@ -590,17 +679,17 @@ def main(argv=None):
             x = gpu_leg(args, cid, e2, 0, 1, n_steps, n_warm, one_hot=one_hot, **kw)
             ls = x["gpu_s"] / (n_steps / Tx)
             b2 = algorithmic_bytes_per_env_step(x["spec"], one_hot=one_hot, steps_per_launch=Tx)
-            b1 = algorithmic_bytes_per_env_step(x["spec"], one_hot=one_hot)
-            tr = measured_traffic(n2, e2) if not label else None
+            Sx = kw.get("stream_shards", 1)
+            plain = not (one_hot or kw.get("graph") or Tx > 1 or "allow_agent_overlap" in kw)
+            tr = measured_traffic(n2, e2, Sx) if plain else None
             extra.append({"baseline_config": cid, "workload": f"{n2}, {a2} agents, {e2} envs" + (", " + label if label else ""),
                           "value": e2 * a2 * n_steps / x["wall"], "launch_us": ls * 1e6, "steps_per_launch": Tx,
                           "stream_shards": kw.get("stream_shards", 1),
                           "us_per_step": ls / Tx * 1e6, "algorithmic_bytes_per_env_step": b2,
+                          # (a fused launch needs fewer bytes per step - the state travels once per launch - and is
+                          # priced at its own bytes; compare times through `us_per_step`)
                           "roofline_frac": e2 * b2 * Tx / ls / 1e9 / HBM_PEAK_GBS,
-                          # a fused launch needs fewer bytes per step (the state travels once per launch): the same
-                          # time per step priced at the bytes of one-step launches, for comparing times
-                          "roofline_frac_at_one_step_bytes": e2 * b1 * Tx / ls / 1e9 / HBM_PEAK_GBS,
-                          "roofline_frac_counter_bytes": (tr / ls / 1e9 / HBM_PEAK_GBS) if tr else None,
+                          "roofline_frac_counter_bytes": (tr / (ls / Tx) / 1e9 / HBM_PEAK_GBS) if tr else None,
                           "episodes": int(x["stats"][0])})
 
         for cid in (2, 3, 4, 5):
@@ -648,8 +737,8 @@ def main(argv=None):
         line["cpu_baseline"] = cpu_leg(args.config)
         line["cpu_baseline"]["host_cpus"] = os.cpu_count()
     if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
+        print(json.dumps(check_fractions(line)))
+    if backend is not None:
         torch.distributed.destroy_process_group()
     return 0 if line["collective_check"]["ok"] else 3
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 6
+#define MG_ABI_VERSION 7
 
 /* error codes */
 #define MG_OK 0
@@ -105,6 +105,13 @@ typedef struct MgOut {
     uint8_t *onehot_dev;     /* [E][A][V][V][24] the image as OneHotObsWrapper.observation returns
                                 it (multigrid/wrappers.py:105-146: 11 type, 6 colour and 7 state
                                 planes, wrappers.py:95), written by the same launch; 8-byte aligned */
+    uint8_t *rows_dev;       /* [E][A][8] agent rows (layout at the top of this file) of the state the returned
+                                observation shows: what `agent_states` reads after the call (base.py:587-596 `is_done`,
+                                pettingzoo/__init__.py:48-52 `agents`); 8-byte aligned.  Single-step launches only:
+                                with it mg_step_n takes one launch per step. */
+    double *reward64_dev;    /* [E][A] the step's rewards as the doubles `_reward` computes (base.py:655-659), where
+                                reward_dev holds them rounded to float32; 8-byte aligned; as rows_dev for mg_step_n.
+                                Written by steps only. */
 } MgOut;
 
 typedef struct MgEnv *MgHandle;
@@ -211,7 +218,8 @@ int mg_gen_obs(MgHandle h, const MgOut *out, void *stream);
  * lives in a fixed 8 MiB buffer inside the library (one per GPU, held until the process ends).  A call
  * whose environments do not fit (num_envs * (header + grid bytes), e.g. 13442 environments of 16 x 16 cells
  * and 8 agents, 47661 of 8 x 8 cells and 2 agents) returns MG_EINVAL and mg_last_error(NULL) says how many
- * do.  Fields are taken modulo 16 (heading modulo 4) instead of being checked.  All calls on one GPU share
+ * do.  Fields are taken modulo 16 (heading modulo 4) instead of being checked; an agent outside the grid is
+ * neither drawn nor does it block sight, and its own view is taken from the nearest cell inside.  All calls on one GPU share
  * the buffer: calls that may overlap there (different streams, different threads) race and must be
  * serialised by the caller; calls on one stream are safe back to back. */
 int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint8_t *agents_dev, const MgOut *out,
@@ -226,8 +234,8 @@ int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint
  * taken at pickup time; bit 2 / 3 = the red / blue door's cell was cleared under an eliminated agent (:503);
  * meta[0] / meta[1] = how often the red / blue ball's discount factor has been squared (:452-454).
  * Any pointer may be NULL.  mg_set_state first checks `grid_dev` and `agents_dev` against the field limits
- * at the top of this file (waiting for the stream) and returns MG_EINVAL, leaving the state untouched, when a
- * value does not fit. */
+ * at the top of this file and every agent's position against the grid (x < W, y < H), waiting for the stream,
+ * and returns MG_EINVAL, leaving the state untouched, when a value does not fit. */
 int mg_get_state(MgHandle h, uint8_t *grid_dev, uint8_t *agents_dev, uint8_t *meta_dev,
                  int32_t *steps_dev, uint8_t *flags_dev, void *stream);
 int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,

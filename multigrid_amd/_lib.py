@@ -19,7 +19,7 @@ MG_OK = 0
 KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY, KIND_COMPETITIVE = range(5)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
@@ -38,7 +38,8 @@ class MgConfig(ctypes.Structure):
 
 class MgOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev", "onehot_dev")]
+        "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev", "onehot_dev",
+        "rows_dev", "reward64_dev")]
 
 
 class MgLayoutSpec(ctypes.Structure):
@@ -47,18 +48,58 @@ class MgLayoutSpec(ctypes.Structure):
         "max_keys_per_room")] + [("agent_color", ctypes.c_uint8 * 64)]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH) and \
-            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(SRC_PATH),
-                                              os.path.getmtime(os.path.join(INCLUDE_DIR, "mgrid.h"))):
-        return LIB_PATH
+def kernel_resources(listing: str):
+    """Registers and spills of every kernel in a device assembly listing (the `amdhsa.kernels` metadata hipcc
+    writes at its end): ``{mangled name: {vgpr_count, agpr_count, sgpr_count, sgpr_spill_count, vgpr_spill_count,
+    private_segment_fixed_size, group_segment_fixed_size}}``."""
+    import re
+    text = open(listing).read()
+    at = text.find("amdhsa.kernels:")
+    out = {}
+    if at < 0:
+        return out
+    for entry in re.split(r"\n  - ", text[at:])[1:]:
+        name = re.search(r"\.name:\s+(\S+)", entry)
+        if not name:
+            continue
+        rec = {}
+        for key in ("vgpr_count", "agpr_count", "sgpr_count", "sgpr_spill_count", "vgpr_spill_count",
+                    "private_segment_fixed_size", "group_segment_fixed_size"):
+            m = re.search(r"\.%s:\s+(\d+)" % key, entry)
+            rec[key] = int(m.group(1)) if m else 0
+        out[name.group(1)] = rec
+    return out
+
+
+def _demangle(names):
+    import shutil
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt", path="/opt/rocm/lib/llvm/bin")
+    if not tool:
+        return list(names)
+    r = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True)
+    got = r.stdout.split("\n")[:len(names)]
+    return got if r.returncode == 0 and len(got) == len(names) else list(names)
+
+
+REGISTERS_PATH = os.path.join(PKG_DIR, "kernel_registers.json")
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str | None = None) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    The build keeps its intermediate files in a scratch directory and looks at the device assembly before the
+    library is put in place: every kernel's register and spill counts are listed (``kernel_registers.json`` beside
+    the library; printed with ``verbose``), a step kernel that spills vector registers to scratch memory fails the
+    build, and so does a code pattern this compiler was seen to get wrong (see _isa_lint.py)."""
+    target = out_path or LIB_PATH
+    sources = [SRC_PATH, os.path.join(PKG_DIR, "csrc", "mgrid_experiment.h"), os.path.join(INCLUDE_DIR, "mgrid.h")]
+    if not force and os.path.exists(target) and os.path.getmtime(target) >= max(os.path.getmtime(f) for f in sources):
+        return target
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -Os, measured: the step kernel is 7 % faster than at -O3 (smaller code, and 126 instead of 129 vector
     # registers, which lets a fourth wavefront onto every SIMD)
-    # The build keeps its intermediate files in a scratch directory so that the device assembly can be checked
-    # for a code pattern this compiler was seen to get wrong (see _isa_lint.py) before the library is put in place.
     import glob
+    import json
     import shutil
     import tempfile
     from ._isa_lint import find_masked_copies
@@ -66,13 +107,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     try:
         out = os.path.join(tmp, "libmgrid_hip.so")
         cmd = [hipcc, "-Os", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-save-temps",
-               "-I", INCLUDE_DIR, SRC_PATH, "-o", out]
+               "-I", INCLUDE_DIR, *extra_flags, SRC_PATH, "-o", out]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=tmp)
         listings = glob.glob(os.path.join(tmp, "*gfx950*.s"))
         if not listings:
             raise RuntimeError("the build left no device assembly to check")
+        report = {}
         for path in listings:
             hits = find_masked_copies(path)
             if hits:
@@ -80,10 +122,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError(f"device code writes vector registers before a divergent region's lanes are "
                                    f"switched back on ({len(hits)} place(s): {what}); change the source around the "
                                    "named kernel until the compiler stops doing that")
-        shutil.move(out, LIB_PATH)
+            res = kernel_resources(path)
+            for mangled, plain in zip(res, _demangle(list(res))):
+                report[plain.replace("(anonymous namespace)::", "")] = res[mangled]
+        # template arguments of mg_tile_kernel: view, see-through, MODE (0 = step), ...
+        spilling = [k for k, r in report.items() if "mg_tile_kernel" in k and
+                    (r["vgpr_spill_count"] or r["private_segment_fixed_size"])]
+        if verbose:
+            for k in sorted(report):
+                r = report[k]
+                print(f"  {r['vgpr_count']:3d} vgpr {r['sgpr_count']:3d} sgpr  spills {r['sgpr_spill_count']:3d} s / "
+                      f"{r['vgpr_spill_count']:3d} v  scratch {r['private_segment_fixed_size']:4d} B  {k}")
+        if spilling:
+            raise RuntimeError(f"{len(spilling)} instantiation(s) of the tile kernel spill vector registers to scratch "
+                               f"memory, e.g. {spilling[0]}: {report[spilling[0]]}")
+        # a new inode, renamed into place: processes that have the old library mapped keep the old file
+        staged = f"{target}.tmp.{os.getpid()}"
+        shutil.copy2(out, staged)
+        os.replace(staged, target)
+        if out_path is None:
+            with open(REGISTERS_PATH, "w") as f:
+                json.dump(report, f, indent=1, sort_keys=True)
+                f.write("\n")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return LIB_PATH
+    return target
 
 
 _lib = None

@@ -25,6 +25,8 @@ class StepOutput:
     terminated: torch.Tensor  # uint8 [E, A]
     truncated: torch.Tensor   # uint8 [E, A]
     onehot: Optional[torch.Tensor] = None  # uint8 [E, A, V, V, 24], multigrid/wrappers.py:114-146
+    rows: Optional[torch.Tensor] = None      # uint8 [E, A, 8] agent rows of the state the observation shows
+    reward64: Optional[torch.Tensor] = None  # float64 [E, A] the rewards as the reference's doubles
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -113,7 +115,8 @@ class BatchedMultiGrid:
     @staticmethod
     def _make_out(o: StepOutput) -> MgOut:
         p = lambda t: None if t is None else t.data_ptr()
-        return MgOut(p(o.image), p(o.direction), p(o.reward), p(o.terminated), p(o.truncated), p(o.onehot))
+        return MgOut(p(o.image), p(o.direction), p(o.reward), p(o.terminated), p(o.truncated), p(o.onehot),
+                     p(o.rows), p(o.reward64))
 
     def _stream(self):
         """The current torch stream of this device as a ``hipStream_t``."""

@@ -45,6 +45,7 @@
 #include <mutex>
 
 #include "mgrid.h"
+#include "mgrid_experiment.h"  // MG_EXP / MG_STAMP / MG_TICK: empty unless this is a diagnostic build
 
 // Device memory of mg_gen_obs_of_state(), the one entry point that must not allocate: the packed copy of the
 // caller's state lives here instead of in buffers of a handle.  Every GPU the library runs on holds its own
@@ -152,7 +153,9 @@ struct KParams {
     int max_steps;
     int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
     int GP;  // distance between two environments' grids in LDS: GS + 16 (a tuning build may widen it)
-    uint32_t magic_a, magic_nc, magic_per;  // multiply-high constants for division by A, A + 2 and GS / 16
+    int HP;  // distance between two environments' header blocks in LDS: HS, or HS + 16 where HS / 16 is even (an odd
+             // number of 16-byte slots spreads one-lane-per-environment accesses over all banks)
+    uint32_t magic_a, magic_nc, magic_per, magic_ph;  // multiply-high constants for division by A, A + 2, GS / 16, HS / 16
     uint32_t env_offset;
     uint64_t seed;
     uint32_t serial;  // reset launches so far (0: the first reset starts the episode counters)
@@ -176,11 +179,13 @@ struct KParams {
     float *reward;
     uint8_t *terminated;
     uint8_t *truncated;
+    uint8_t *rows_out;   // [E][A][8] agent rows as the launch leaves them in the returned observation's state
+    double *reward64;    // [E][A] the rewards as the doubles the reference computes
     LdsMap o;
-#ifdef MGRID_EXPERIMENT
-    int dbg;  // phase-ablation bits of the diagnostic build (tools/exp_phase.py); never in the product build
-    unsigned long long *dbg_buf;  // [tiles][32] clock stamps of the diagnostic build
-#endif
+    MG_EXP(
+    int dbg;
+    unsigned long long *dbg_buf;
+    )
 };
 
 // A kernel argument read where it is needed instead of at kernel entry: the compiler loads a by-value argument
@@ -306,24 +311,6 @@ __device__ __forceinline__ double reward_times(double R, int m) {
     return v;
 }
 
-#ifdef MGRID_EXPERIMENT
-// Diagnostic build only: drain memory, read the shader clock, keep it in a buffer of its own.
-#define MG_STAMP(k)                                                                        \
-    do {                                                                                   \
-        if (p.dbg_buf && !(p.dbg & 16)) {                                                  \
-            __builtin_amdgcn_s_waitcnt(0);                                                 \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                    \
-            if (threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + (k)] = t_; \
-        }                                                                                  \
-    } while (0)
-// Light stamp: no drain, so the pipeline keeps running; accumulates a time difference instead.
-#define MG_TICK(var)                                                                       \
-    do {                                                                                   \
-        if (p.dbg_buf && (p.dbg & 16)) var = __builtin_amdgcn_s_memtime();                 \
-    } while (0)
-#else
-#define MG_STAMP(k) do { } while (0)
-#endif
 
 // ---- act: one lane per environment -------------------------------------------------------------
 
@@ -503,7 +490,7 @@ __device__ __forceinline__ void hook_failure(const KParams &p, EnvView &ev, int 
 // later readers of the same cell consult.
 __device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
     const int A = p.A();
-    uint8_t *h = lds + p.o.hdr + slot * p.HS;
+    uint8_t *h = lds + p.o.hdr + slot * p.HP;
     EnvView ev;
     ev.A = A;
     ev.rows = h + H_ROWS;
@@ -756,17 +743,17 @@ __device__ __forceinline__ void store_bytes(uint8_t *ptr, uint64_t w, int A) {
 template <bool COMP>
 __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env, uint64_t actw, uint64_t ordw) {
     const int A = p.A(), H = p.H();
-    uint8_t *h = lds + p.o.hdr + slot * p.HS;
+    uint8_t *h = lds + p.o.hdr + slot * p.HP;
     uint8_t *rows = h + H_ROWS;
     const uint16_t *fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
     uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
     const uint64_t ones = 0x0101010101010101ull >> (8 * (8 - A));  // byte k = 1 for k < A
 
     if (*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot) & ACT_FINISHED) return;
-#ifdef MGRID_EXPERIMENT
+    MG_EXP(
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
     MG_TICK(q0);
-#endif
+    )
     const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
     const int step = static_cast<int>(h0.x) + 1;  // base.py:395
     *reinterpret_cast<int *>(h + H_STEP) = step;
@@ -799,9 +786,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                 ordw ^= (d << (8 * k)) ^ (d << (8 * j));
             }
         }
-#ifdef MGRID_EXPERIMENT
-        MG_TICK(q1);
-#endif
+        MG_EXP(MG_TICK(q1);)
         const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
         const uint64_t setw = everyone ? ones : load_bytes(lds + p.o.tout + slot * A, A);  // byte k: agent k acts here
         termw = 0;
@@ -841,9 +826,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
     }
     if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559: a reward paid to one is paid to all
-#ifdef MGRID_EXPERIMENT
-    MG_TICK(q2);
-#endif
+    MG_EXP(MG_TICK(q2);)
 
     // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
     store_bytes(lds + p.o.oterm + slot * A, termw, A);
@@ -1049,9 +1032,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     if (p.kind() == MG_KIND_LOCKEDHALLWAY && __popc(flags & FLAG_LH_MASK) == p.num_rooms())
         toutw = ones;  // locked_hallway.py:213-215: only the returned dict
 
-#ifdef MGRID_EXPERIMENT
-    MG_TICK(q3);
-#endif
+    MG_EXP(MG_TICK(q3);)
     store_bytes(lds + p.o.tout + slot * A, toutw, A);
     store_bytes(lds + p.o.rewm + slot * A, rewmw, A);
     const bool all_term = toutw == ones;
@@ -1092,16 +1073,17 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
         }
     }
-#ifdef MGRID_EXPERIMENT
+    // (diagnostic builds: header read + reward + order draw, the agents' actions, hooks, flags + statistics + cells to HBM)
+    MG_EXP(
     MG_TICK(q4);
     if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
         unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 25;
-        d[0] = q1 - q0;  // header read, reward, order draw
-        d[1] = q2 - q1;  // the agents' actions
-        d[2] = q3 - q2;  // hooks
-        d[3] = q4 - q3;  // flags, statistics, cells to HBM
+        d[0] = q1 - q0;
+        d[1] = q2 - q1;
+        d[2] = q3 - q2;
+        d[3] = q4 - q3;
     }
-#endif
+    )
 }
 
 // ---- act, one lane per environment, for exactly AC = 2 or 4 agents ---------------------------------------
@@ -1135,7 +1117,7 @@ __device__ __forceinline__ void act_env_fixed(const KParams &p, uint8_t *lds, in
     static_assert(AC == 2 || AC == 4, "two or four agents: their bytes fill a 16- or 32-bit word");
     constexpr uint32_t ones = AC == 4 ? 0x01010101u : 0x0101u;  // byte k = 1 for every agent k
     const int H = p.H();
-    uint8_t *h = lds + p.o.hdr + slot * p.HS;
+    uint8_t *h = lds + p.o.hdr + slot * p.HP;
     const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
     if (fl0 & ACT_FINISHED) return;
     auto bytes_at = [&](int off) -> uint32_t {  // the environment's AC bytes of a per-agent byte array
@@ -1359,7 +1341,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                                           int my_slot, int my_agent) {
     const int A = p.A();
     const bool mine = lane < ns * A;
-    uint8_t *h = lds + p.o.hdr + (s0 + my_slot) * p.HS;
+    uint8_t *h = lds + p.o.hdr + (s0 + my_slot) * p.HP;
     uint8_t *a = h + H_ROWS + 8 * my_agent;
     uint2 *pair = reinterpret_cast<uint2 *>(lds + p.o.img);
     uint2 r0 = make_uint2(0u, 0u);
@@ -1633,7 +1615,7 @@ __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int s
     // (restarts are rare: the pool's addresses are fetched here rather than kept for the whole step)
     const uint4 *sh = reinterpret_cast<const uint4 *>(late_arg<const uint8_t *>(offsetof(KParams, pool_hdr)) + static_cast<size_t>(layout) * p.HS);
     const uint4 *sg = reinterpret_cast<const uint4 *>(late_arg<const uint8_t *>(offsetof(KParams, pool_grid)) + static_cast<size_t>(layout) * p.GS);
-    uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr + slot * p.HS);
+    uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr + slot * p.HP);
     uint4 *gg = reinterpret_cast<uint4 *>(p.grid + static_cast<size_t>(env) * p.GS);
     for (int i = lane; i < p.HS / 16; i += 64) {
         uint4 v = sh[i];
@@ -1885,15 +1867,14 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     int *lsrc = reinterpret_cast<int *>(lds + p.o.src);
 
     MG_STAMP(0);
-#ifdef MGRID_EXPERIMENT
+    // (diagnostic builds: MGRID_DBG bit 6 delays the tiles whose index has bit ((dbg >> 16) & 31) set by
+    // ((dbg >> 8) & 255) sleeps of 127 x 64 clocks, so that the wavefronts of a SIMD are not all in the same phase)
+    MG_EXP(
     unsigned long long tstart = 0;
     MG_TICK(tstart);
-    // Staggered start (diagnostic): MGRID_DBG bit 6 delays the tiles whose index has bit ((dbg >> 16) & 31) set by
-    // ((dbg >> 8) & 255) sleeps of 127 x 64 clocks, so that the wavefronts sharing a SIMD are not all in the same
-    // phase of the step at the same time.
     if ((p.dbg & 64) && ((blockIdx.x >> ((p.dbg >> 16) & 31)) & 1))
         for (int i = 0, n = (p.dbg >> 8) & 255; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
+    )
     constexpr bool small = SMALLA;  // A <= 8, chosen by the host
     // which environments take part (a masked reset skips some)
     bool active = lane < net;
@@ -1903,11 +1884,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
 
     const int per = p.GS / 16;
     const bool want_img = p.image != nullptr || (OH && p.onehot != nullptr);
-#ifdef MGRID_EXPERIMENT
-    const bool passes = (want_img || MODE == MODE_STEP) && !(p.dbg & 32);
-#else
-    const bool passes = want_img || MODE == MODE_STEP;
-#endif
+    const bool passes = (want_img || MODE == MODE_STEP) MG_EXP(&& !(p.dbg & 32));
     // Grid blocks travel HBM -> registers -> LDS one sub-tile ahead: the loads for sub-tile g + 1
     // are issued before sub-tile g is computed and land in LDS after its observation has read
     // the previous grid, just before its image is stored; so neither the load latency nor the
@@ -2013,12 +1990,15 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (MULTI) load_all_grids(); else
         if (passes && MODE != MODE_RESET) issue(0);
         wave_sync();
-        if (lane < nh) dh[lane] = hb0;
-        if (64 + lane < nh) dh[64 + lane] = hb1;
-        if (128 + lane < nh) dh[128 + lane] = hb2;
-        if (192 + lane < nh) dh[192 + lane] = hb3;
+        // (in LDS the blocks lie HP bytes apart: piece i of the contiguous HBM block belongs to environment i / (HS / 16))
+        const int hpad = (p.HP - p.HS) >> 4;
+        auto hslot = [&](int i) { return hpad ? i + hpad * udiv(i, p.magic_ph) : i; };
+        if (lane < nh) dh[hslot(lane)] = hb0;
+        if (64 + lane < nh) dh[hslot(64 + lane)] = hb1;
+        if (128 + lane < nh) dh[hslot(128 + lane)] = hb2;
+        if (192 + lane < nh) dh[hslot(192 + lane)] = hb3;
 #pragma unroll 1
-        for (int i = 256 + lane; i < nh; i += 64) dh[i] = sh[i];
+        for (int i = 256 + lane; i < nh; i += 64) dh[hslot(i)] = sh[i];
         if (MODE == MODE_STEP) {
             if (words && 4 * lane + 4 <= nag) {
                 *reinterpret_cast<uint32_t *>(lds + p.o.act + 4 * lane) = aw;
@@ -2064,7 +2044,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     if (MODE != MODE_STEP) {
         for (int s = lane; s < nag; s += 64) {
             const int slot = udiv(s, p.magic_a);
-            lds[p.o.oterm + s] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_TERM];
+            lds[p.o.oterm + s] = lds[p.o.hdr + slot * p.HP + H_ROWS + 8 * (s - slot * A) + R_TERM];
         }
         wave_sync();
     }
@@ -2073,10 +2053,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     // ---- act ---------------------------------------------------------------------------------------
     const int my_slot = udiv(lane, p.magic_a);  // environment (within a sub-tile) of this lane's agent
     const int my_agent = lane - my_slot * A;
-#ifdef MGRID_EXPERIMENT
+    MG_EXP(
     unsigned long long ta0 = 0, ta1 = 0, ta2 = 0, tc = 0;
     MG_TICK(ta0);
-#endif
+    )
     int t = 0;
     // multi-step kernel: the next step's action and order words, loaded while this step's views are made
     uint32_t aw_next = 0, ow_next = 0;
@@ -2113,10 +2093,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = ACT_REPLAY_ALL;  // every agent acts in order
         }
         wave_sync();
-#ifdef MGRID_EXPERIMENT
+        MG_EXP(
         MG_TICK(ta1);
         const int n_replay = __popcll(__ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0));
-#endif
+        )
         // environments that act_lanes() could not finish: hooks, or agents whose actions interact
         if (__ballot(lane < net && !(*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * lane) & ACT_FINISHED)) != 0 &&
             lane < net) {
@@ -2133,16 +2113,17 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             }
         }
         wave_sync();
-#ifdef MGRID_EXPERIMENT
+        // (diagnostic builds: staging, act with a lane per agent, act with a lane per environment, replayed environments)
+        MG_EXP(
         MG_TICK(ta2);
         if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
             unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 20;
-            d[0] = ta0 - tstart;  // staging
-            d[1] = ta1 - ta0;     // act, lane per agent
-            d[2] = ta2 - ta1;     // act, lane per environment
-            d[4] = n_replay;      // environments whose agents' actions had to be replayed in order
+            d[0] = ta0 - tstart;
+            d[1] = ta1 - ta0;
+            d[2] = ta2 - ta1;
+            d[4] = n_replay;
         }
-#endif
+        )
         MG_STAMP(2);
         if (MULTI && t + 1 < p.T) {
             // the act phase has consumed this step's actions: the next step's set out now and arrive during the views
@@ -2162,7 +2143,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                     const int s = __builtin_ctzll(m);
                     m &= m - 1;
                     const int env = e0 + s;
-                    const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HS + H_EPISODE) + 1u;
+                    const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HP + H_EPISODE) + 1u;
                     const int layout = pick_layout(p, env, episode);
                     wave_sync();
                     reload_env(p, lds, s, env, layout, episode, lane);
@@ -2170,10 +2151,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                     if (lane == 0) lds[p.o.flag + 4 * s + 2] = 0;  // the fresh grid takes no patches
                     if (lane == 0) lds[p.o.flag + 4 * s + 3] = 0;
                     wave_sync();
-                    if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HS + H_ROWS + 8 * lane + R_TERM];
+                    if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HP + H_ROWS + 8 * lane + R_TERM];
                     if (COMP && lane < A)  // nothing of the hook is left to apply: the agents stand where the layout puts them
                         reinterpret_cast<uint16_t *>(lds + p.o.pxy)[s * A + lane] =
-                            *reinterpret_cast<const uint16_t *>(lds + p.o.hdr + s * p.HS + H_ROWS + 8 * lane);
+                            *reinterpret_cast<const uint16_t *>(lds + p.o.hdr + s * p.HP + H_ROWS + 8 * lane);
                 }
                 wave_sync();
             }
@@ -2192,13 +2173,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             commit(0);
         }
         wave_sync();
-#ifdef MGRID_EXPERIMENT
+        MG_EXP(
         {
             unsigned long long tb = 0;
             MG_TICK(tb);
             if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 29] = tb - ta2;
         }
-#endif
+        )
         for (int s0 = 0; s0 < net; s0 += NE) {
             const int ns = min(NE, net - s0);
             const int np = ns * A;
@@ -2206,13 +2187,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             const bool all_active = sub_mask == ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
             const bool has_next = !MULTI && s0 + NE < net;
             const int gslot0 = MULTI ? s0 : 0;  // where the sub-tile's grids start in LDS
-#ifdef MGRID_EXPERIMENT
+            MG_EXP(
             unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
             MG_TICK(tk0);
-#endif
+            )
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
-            const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HS;
+            const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HP;
             uint16_t *my_grid = reinterpret_cast<uint16_t *>(lds + p.o.grid + (gslot0 + my_slot) * p.GP);
             if (MODE == MODE_STEP) {
                 // cells changed by this step, replayed in order (one lane per environment)
@@ -2241,13 +2222,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             auto refresh_front = [&](uint32_t row_x) {
                 if (mine) {
                     const uint32_t fi = front_index(p, row_x);
-                    reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HS + p.HFC)[my_agent] =
+                    reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HP + p.HFC)[my_agent] =
                         fi == FC_NONE ? static_cast<uint16_t>(0) : my_grid[fi];
                 }
                 // (a step of CompetativeRedBlueDoor environments is always a COMP launch)
                 const bool comp_env = COMP || (MODE != MODE_STEP && p.comp());
                 if ((p.kind() == MG_KIND_REDBLUEDOORS || comp_env) && lane < ns && ((sub_mask >> lane) & 1)) {
-                    uint8_t *h = lds + p.o.hdr + (s0 + lane) * p.HS;
+                    uint8_t *h = lds + p.o.hdr + (s0 + lane) * p.HP;
                     uint32_t meta = *reinterpret_cast<const uint32_t *>(h + H_META);
                     if (comp_env)  // the doors of competative_red_blue_door.py:201-211 never move
                         meta = static_cast<uint32_t>(p.W() / 4) | (static_cast<uint32_t>(p.H() - 2) << 8) |
@@ -2268,9 +2249,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             // environments draw nothing, obs.py:166-167).
             bool draw = false;  // this lane's agent is drawn at cell `ci`, which held `under`
             uint32_t ci = 0, under = 0;
-#ifdef MGRID_EXPERIMENT
-            if (!(p.dbg & 8))
-#endif
+            MG_EXP(if (!(p.dbg & 8)))
             if (want_img && A > 1) {
                 // LDS writes of one wavefront land in program order, so drawing the agents index by index
                 // leaves the highest one on a shared cell without looking at the other agents at all
@@ -2298,9 +2277,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             uint32_t px[NPX];
 #pragma unroll
             for (int k = 0; k < NPX; ++k) px[k] = 0u;
-#ifdef MGRID_EXPERIMENT
-            if (!(p.dbg & 1))
-#endif
+            MG_EXP(if (!(p.dbg & 1)))
             if (want_img && mine)
                 observe_agent<V, SEE, WALLED>(p, my_row, lds + p.o.grid + (gslot0 + my_slot) * p.GP, px);
             wave_sync();
@@ -2320,7 +2297,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 if (mine) {
                     const uint32_t xy = reinterpret_cast<const uint16_t *>(lds + p.o.pxy)[(s0 + my_slot) * A + my_agent];
                     row_x = (row_x & 0xFFFF0000u) | xy;
-                    *reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HS + H_ROWS + 8 * my_agent) =
+                    *reinterpret_cast<uint16_t *>(lds + p.o.hdr + (s0 + my_slot) * p.HP + H_ROWS + 8 * my_agent) =
                         static_cast<uint16_t>(xy);
                 }
                 wave_sync();
@@ -2330,14 +2307,10 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             // The next sub-tile's grids set out now, travel while this sub-tile's images are stored and
             // replace this sub-tile's grids in LDS at the end of the pass; they occupy registers only
             // while the observation's own are free.
-#ifdef MGRID_EXPERIMENT
-            MG_TICK(tk1);
-#endif
+            MG_EXP(MG_TICK(tk1);)
             if (has_next) issue(s0 + NE);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef MGRID_EXPERIMENT
-            MG_TICK(tk2);
-#endif
+            MG_EXP(MG_TICK(tk2);)
 
             if (s0 == 0) MG_STAMP(7);
             // Images leave through a small LDS buffer, STG agents at a time: their lanes lay the
@@ -2345,9 +2318,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             // The stream sits `shift` bytes into the buffer so that LDS and HBM agree modulo 16.
             const size_t tile_agent0 = static_cast<size_t>(e0 + s0) * A;  // first agent of the sub-tile
             const size_t tile_base = tile_agent0 * IMG;  // byte offset of the sub-tile's images
-#ifdef MGRID_EXPERIMENT
-            if (!(p.dbg & 2))
-#endif
+            MG_EXP(if (!(p.dbg & 2)))
             if (want_img && all_active && np % STG == 0 &&
                 (out_image == nullptr || ((reinterpret_cast<uintptr_t>(out_image) + tile_base) & 15) == 0)) {
                 // whole blocks, 16-byte aligned in HBM (STG * IMG is a multiple of 16)
@@ -2441,16 +2412,17 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 wave_sync();
             }
             if (s0 == 0) MG_STAMP(8);
-#ifdef MGRID_EXPERIMENT
+            // (diagnostic builds: compute, commit of the prefetched grids, copy-out, per pass)
+            MG_EXP(
             MG_TICK(tk3);
             if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
                 unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 16;
-                d[0] += tk1 - tk0;  // compute (patch .. observe)
-                d[1] += tk2 - tk1;  // commit (wait for the prefetched grids, write them to LDS)
-                d[2] += tk3 - tk2;  // copy-out (LDS reads + store issue)
+                d[0] += tk1 - tk0;
+                d[1] += tk2 - tk1;
+                d[2] += tk3 - tk2;
                 d[3] += 1;
             }
-#endif
+            )
         }
     }
 
@@ -2467,7 +2439,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         const int slot = udiv(s, p.magic_a);
         if (!((active_mask >> slot) & 1)) continue;
         const size_t o = static_cast<size_t>(e0) * A + s;
-        if (out_direction) out_direction[o] = lds[p.o.hdr + slot * p.HS + H_ROWS + 8 * (s - slot * A) + R_DIR];
+        if (out_direction) out_direction[o] = lds[p.o.hdr + slot * p.HP + H_ROWS + 8 * (s - slot * A) + R_DIR];
         if (MODE == MODE_STEP) {
             if (out_reward)
                 out_reward[o] = COMP ? static_cast<float>(reinterpret_cast<const double *>(lds + p.o.racc)[s])
@@ -2475,12 +2447,18 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (out_terminated) out_terminated[o] = lds[p.o.tout + s];
             if (out_truncated) out_truncated[o] = lds[p.o.flag + 4 * slot];
         }
+        if constexpr (!MULTI) {  // optional outputs of single-step launches (callers that mirror one environment on the host)
+            if (uint2 *out_rows = late_arg<uint2 *>(offsetof(KParams, rows_out)))
+                out_rows[o] = *reinterpret_cast<const uint2 *>(lds + p.o.hdr + slot * p.HP + H_ROWS + 8 * (s - slot * A));
+            if (MODE == MODE_STEP)
+                if (double *out_reward64 = late_arg<double *>(offsetof(KParams, reward64)))
+                    out_reward64[o] = COMP ? reinterpret_cast<const double *>(lds + p.o.racc)[s]
+                                           : reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]);
+        }
     }
 
     MG_STAMP(9);
-#ifdef MGRID_EXPERIMENT
-    MG_TICK(tc);
-#endif
+    MG_EXP(MG_TICK(tc);)
     if (MODE == MODE_STEP && p.autoreset() == MG_AUTORESET_NEXT_STEP) {
         uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
         if (m) {
@@ -2489,7 +2467,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 const int s = __builtin_ctzll(m);
                 m &= m - 1;
                 const int env = e0 + s;
-                const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HS + H_EPISODE) + 1u;
+                const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HP + H_EPISODE) + 1u;
                 wave_sync();
                 const int layout = pick_layout(p, env, episode);
                 reload_env(p, lds, s, env, layout, episode, lane);
@@ -2517,22 +2495,24 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         // header blocks back to HBM (reset mode: only the environments that were reset)
         uint4 *dh = reinterpret_cast<uint4 *>(late_arg<uint8_t *>(offsetof(KParams, hdr)) + static_cast<size_t>(e0) * p.HS);
         const uint4 *sh = reinterpret_cast<const uint4 *>(lds + p.o.hdr);
-        const int per_h = p.HS / 16;
-        for (int i = lane; i < net * per_h; i += 64)
-            if ((active_mask >> udiv(i, per_h == 1 ? 0u : (0xFFFFFFFFu / per_h + 1u))) & 1) dh[i] = sh[i];
+        const int per_h = p.HS / 16, hpad = (p.HP - p.HS) >> 4;
+        for (int i = lane; i < net * per_h; i += 64) {
+            const int slot = udiv(i, p.magic_ph);
+            if ((active_mask >> slot) & 1) dh[i] = sh[i + hpad * slot];
+        }
     }
     MG_STAMP(10);
-#ifdef MGRID_EXPERIMENT
+    MG_EXP(
     {
         unsigned long long tend = 0;
         MG_TICK(tend);
         if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
             p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 23] = tend - tstart;
-            p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 30] = tend - tc;  // restarts, header blocks back to HBM
+            p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 30] = tend - tc;
             p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 31] = tc - tstart;
         }
     }
-#endif
+    )
 }
 
 // ---- reference-layout <-> device-layout conversion (debug / parity path) -------------------------------
@@ -2561,19 +2541,21 @@ __global__ void mg_set_state_kernel(KParams p, const uint8_t *grid, const uint8_
     }
 }
 
-// Fields the packed formats cannot hold (type, colour, state above 15; a heading above 3): counted, so
-// that mg_set_state can refuse the state instead of truncating it.
+// Fields the packed formats cannot hold (type, colour, state above 15; a heading above 3) and agents that stand
+// outside the grid (which mg_upload_layouts refuses as well): counted, so that mg_set_state can refuse the state
+// instead of truncating it.  Cells and agent rows are walked in loops of their own: there may be more rows than cells.
 __global__ void mg_validate_state_kernel(KParams p, const uint8_t *grid, const uint8_t *agents, int *bad) {
     const size_t cells = static_cast<size_t>(p.E) * p.W() * p.H(), rows = static_cast<size_t>(p.E) * p.A();
+    const size_t first = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     int n = 0;
-    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < cells;
-         i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        if (grid) n += (grid[3 * i] > 15) | (grid[3 * i + 1] > 15) | (grid[3 * i + 2] > 15);
-        if (agents && i < rows) {
+    if (grid)
+        for (size_t i = first; i < cells; i += stride) n += (grid[3 * i] > 15) | (grid[3 * i + 1] > 15) | (grid[3 * i + 2] > 15);
+    if (agents)
+        for (size_t i = first; i < rows; i += stride) {
             const uint8_t *r = agents + 8 * i;
-            n += (r[R_DIR] > 3) | (r[R_CT] > 15) | (r[R_CC] > 15) | (r[R_CS] > 15) | (r[R_COLOR] > 15);
+            n += (r[R_X] >= p.W()) | (r[R_Y] >= p.H()) | (r[R_DIR] > 3) | (r[R_CT] > 15) | (r[R_CC] > 15) | (r[R_CS] > 15) |
+                 (r[R_COLOR] > 15);
         }
-    }
     if (n) atomicAdd(bad, n);
 }
 
@@ -2929,6 +2911,13 @@ __global__ void mg_generate_layouts_kernel(KParams p, MgLayoutSpec ls, uint8_t *
 
 thread_local std::string g_create_error;
 
+// Tuning and test switches are read from the environment only when MGRID_TUNING=1 says so: by default what the
+// library does depends on its arguments alone.
+const char *tuning_env(const char *name) {
+    const char *on = getenv("MGRID_TUNING");
+    return (on && on[0] == '1' && on[1] == 0) ? getenv(name) : nullptr;
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -3107,8 +3096,9 @@ int scratch_for_device(int device, uint8_t **ptr) {
     return MG_OK;
 }
 
-bool out_ok(const MgOut *out) {  // the one-hot image is written in 8-byte pieces
-    return !out || (reinterpret_cast<uintptr_t>(out->onehot_dev) & 7) == 0;
+bool out_ok(const MgOut *out) {  // the one-hot image, the agent rows and the double rewards are written in 8-byte pieces
+    return !out || ((reinterpret_cast<uintptr_t>(out->onehot_dev) | reinterpret_cast<uintptr_t>(out->rows_dev) |
+                     reinterpret_cast<uintptr_t>(out->reward64_dev)) & 7) == 0;
 }
 
 void set_out(KParams &kp, const MgOut *out, int view, int force_stream) {
@@ -3118,6 +3108,8 @@ void set_out(KParams &kp, const MgOut *out, int view, int force_stream) {
     kp.reward = out ? out->reward_dev : nullptr;
     kp.terminated = out ? out->terminated_dev : nullptr;
     kp.truncated = out ? out->truncated_dev : nullptr;
+    kp.rows_out = out ? out->rows_dev : nullptr;
+    kp.reward64 = out ? out->reward64_dev : nullptr;
     // outputs large enough to be streamed past the caches (thresholds measured on MI355X)
     const size_t cells = static_cast<size_t>(kp.E) * kp.A() * view * view;
     kp.bits &= ~(3u << 21);
@@ -3179,6 +3171,10 @@ int configure(MgEnv *h, const MgConfig &c) {
     kp.HFC = 16 + 8 * round_up(c.num_agents, 2);
     kp.HS = round_up(kp.HFC + 2 * (c.num_agents + 2), 16);
     kp.GS = round_up(2 * c.width * c.height, 16);
+#ifndef MG_HDR_PITCH_PAD
+#define MG_HDR_PITCH_PAD 16
+#endif
+    kp.HP = kp.HS + (((kp.HS / 16) & 1) ? 0 : MG_HDR_PITCH_PAD);
     // In LDS 16 bytes separate the grids of a sub-tile, which spreads most grid sizes over the banks.  Making the
     // distance an odd number of 16-byte pieces for every size (MG_ODD_GRID_PITCH: 13 x 9 and 11 x 6 grids then get 32
     // bytes) measured no faster on 65536 x 4 agents of LockedHallway and 2 % slower on 2-agent batches (more LDS
@@ -3198,16 +3194,16 @@ int configure(MgEnv *h, const MgConfig &c) {
     const int img = 3 * c.view_size * c.view_size;
     bool lanes_act = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ||
                      (c.num_agents >= 2 && (c.kind == MG_KIND_EMPTY || c.kind == MG_KIND_REDBLUEDOORS));
-    if (const char *ev = getenv("MGRID_LANES_ACT")) lanes_act = atoi(ev) != 0 && c.num_agents >= 2;  // tuning / test override
+    if (const char *ev = tuning_env("MGRID_LANES_ACT")) lanes_act = atoi(ev) != 0 && c.num_agents >= 2;  // tuning / test override
     lanes_act = lanes_act && c.kind != MG_KIND_COMPETITIVE;
     if (lanes_act) kp.bits |= 1u << 26;
     h->crowd = lanes_act && !c.allow_agent_overlap && c.num_agents >= PARALLEL_ACT_MIN_AGENTS && c.num_agents <= 8;
-    if (const char *ev = getenv("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
+    if (const char *ev = tuning_env("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
     auto lds_for = [&](int ne, int g, bool multi = false, int stg = STAGE_LANES) {
         const int et = ne * g, np = ne * c.num_agents;
         int o = 0;
         auto take = [&](int bytes) { const int at = o; o += round_up(bytes, 16); return at; };
-        kp.o.hdr = take(et * kp.HS);
+        kp.o.hdr = take(et * kp.HP);
         kp.o.log = take(4 * et * c.num_agents);
         kp.o.act = take(et * c.num_agents);
         kp.o.ord = take(et * c.num_agents);
@@ -3254,8 +3250,8 @@ int configure(MgEnv *h, const MgConfig &c) {
     while ((g + 1) * ne <= et_target && (shape_envs + (g + 1) * ne - 1) / ((g + 1) * ne) >= want_waves &&
            lds_for(ne, g + 1) <= 24 * 1024)
         ++g;
-    if (const char *ev = getenv("MGRID_STREAM")) h->force_stream = atoi(ev) != 0;  // tuning override: "0" / "1"
-    if (const char *ev = getenv("MGRID_TILE")) {  // tuning override: "NE,G"
+    if (const char *ev = tuning_env("MGRID_STREAM")) h->force_stream = atoi(ev) != 0;  // tuning override: "0" / "1"
+    if (const char *ev = tuning_env("MGRID_TILE")) {  // tuning override: "NE,G"
         int a = 0, b = 0;
         if (sscanf(ev, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1 && a * c.num_agents <= 64 && a * b <= 64) {
             ne = a;
@@ -3267,7 +3263,7 @@ int configure(MgEnv *h, const MgConfig &c) {
         h->o_multi = kp.o;
         h->o_multi.oh = 0;
         h->lds_multi = need <= 64 * 1024 ? static_cast<size_t>(need) : 0;
-        if (const char *ev = getenv("MGRID_MULTI_STEP")) h->multi_enabled = atoi(ev) != 0;  // tuning / test override
+        if (const char *ev = tuning_env("MGRID_MULTI_STEP")) h->multi_enabled = atoi(ev) != 0;  // tuning / test override
     }
     {
         // Staging width of the plain step kernel, measured on MI355X.  Launches of at most one round of wavefronts
@@ -3278,7 +3274,7 @@ int configure(MgEnv *h, const MgConfig &c) {
         // at 32 (16 measured 2 % slower there).
         const int tiles = (c.num_envs + ne * g - 1) / (ne * g);
         h->stg_step = h->crowd ? 32 : tiles <= 2048 ? 64 : (lanes_act && c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? 16 : 32);
-        if (const char *ev = getenv("MGRID_STAGE")) {  // tuning / test override
+        if (const char *ev = tuning_env("MGRID_STAGE")) {  // tuning / test override
             const int v = atoi(ev);
             if (!h->crowd && (v == 16 || v == 32 || v == 64)) h->stg_step = v;
         }
@@ -3290,13 +3286,13 @@ int configure(MgEnv *h, const MgConfig &c) {
         h->o_step = kp.o;
     }
     h->lds_bytes = static_cast<size_t>(lds_for(ne, g));
-#ifdef MGRID_EXPERIMENT
-    if (const char *ev = getenv("MGRID_LDS_PAD")) h->lds_bytes += static_cast<size_t>(atoi(ev));
-    if (const char *ev = getenv("MGRID_DBG")) {
+    MG_EXP(
+    if (const char *ev = tuning_env("MGRID_LDS_PAD")) h->lds_bytes += static_cast<size_t>(atoi(ev));
+    if (const char *ev = tuning_env("MGRID_DBG")) {
         kp.dbg = atoi(ev);
-        if (kp.dbg & 32) h->lds_bytes = static_cast<size_t>(kp.o.grid);  // act phase alone
+        if (kp.dbg & 32) h->lds_bytes = static_cast<size_t>(kp.o.grid);
     }
-#endif
+    )
     if (h->lds_bytes + OH_XCHG_BYTES > 64 * 1024)
         return fail(nullptr, MG_EINVAL, "configuration needs %zu bytes of LDS per environment tile", h->lds_bytes);
     kp.geo |= static_cast<uint32_t>(ne) << 24;
@@ -3304,6 +3300,7 @@ int configure(MgEnv *h, const MgConfig &c) {
     kp.magic_a = c.num_agents == 1 ? 0u : 0xFFFFFFFFu / c.num_agents + 1u;
     kp.magic_nc = 0xFFFFFFFFu / (c.num_agents + 2) + 1u;
     kp.magic_per = kp.GS == 16 ? 0u : 0xFFFFFFFFu / (kp.GS / 16) + 1u;
+    kp.magic_ph = kp.HS == 16 ? 0u : 0xFFFFFFFFu / (kp.HS / 16) + 1u;
     h->num_tiles = (c.num_envs + ne * g - 1) / (ne * g);
     return MG_OK;
 }
@@ -3422,12 +3419,21 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
     }
     MG_HIP(h, hipSetDevice(h->cfg.device));
     MG_HIP(h, hipDeviceSynchronize());
-    if (h->pool_hdr) { (void)hipFree(h->pool_hdr); h->pool_hdr = nullptr; }
-    if (h->pool_grid) { (void)hipFree(h->pool_grid); h->pool_grid = nullptr; }
-    MG_HIP(h, hipMalloc(&h->pool_hdr, ph.size()));
-    MG_HIP(h, hipMalloc(&h->pool_grid, pg.size()));
-    MG_HIP(h, hipMemcpy(h->pool_hdr, ph.data(), ph.size(), hipMemcpyHostToDevice));
-    MG_HIP(h, hipMemcpy(h->pool_grid, pg.data(), pg.size(), hipMemcpyHostToDevice));
+    // the new pool is complete on the device before it replaces the old one: a failure leaves the handle as it was
+    uint8_t *nh = nullptr, *ng = nullptr;
+    hipError_t e = hipMalloc(&nh, ph.size());
+    if (e == hipSuccess) e = hipMalloc(&ng, pg.size());
+    if (e == hipSuccess) e = hipMemcpy(nh, ph.data(), ph.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ng, pg.data(), pg.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (nh) (void)hipFree(nh);
+        if (ng) (void)hipFree(ng);
+        return fail(h, MG_EHIP, "mg_upload_layouts: %s", hipGetErrorString(e));
+    }
+    if (h->pool_hdr) (void)hipFree(h->pool_hdr);
+    if (h->pool_grid) (void)hipFree(h->pool_grid);
+    h->pool_hdr = nh;
+    h->pool_grid = ng;
     h->num_layouts = n;
     h->kp.pool_hdr = h->pool_hdr;
     h->kp.pool_grid = h->pool_grid;
@@ -3508,7 +3514,7 @@ int mg_generate_layouts(MgHandle h, const MgLayoutSpec *spec, int32_t n, uint64_
 int mg_reset(MgHandle h, const int32_t *layout_idx_dev, const uint8_t *mask_dev, const MgOut *out, void *stream) {
     if (!h) return MG_EINVAL;
     if (h->num_layouts < 1) return fail(h, MG_ESTATE, "mg_reset: no layouts uploaded");
-    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_reset: onehot_dev must be 8-byte aligned");
+    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_reset: onehot_dev, rows_dev and reward64_dev must be 8-byte aligned");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
     kp.layout_idx = layout_idx_dev;
@@ -3530,7 +3536,7 @@ namespace {
 // what mg_step checks before it launches anything
 int step_ready(MgHandle h, const uint8_t *actions_dev, const MgOut *out) {
     if (!actions_dev) return fail(h, MG_EINVAL, "mg_step: actions_dev is null");
-    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_step: onehot_dev must be 8-byte aligned");
+    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_step: onehot_dev, rows_dev and reward64_dev must be 8-byte aligned");
     if (h->kp.comp() && out && out->onehot_dev)
         return fail(h, MG_EINVAL, "mg_step: one-hot images are not written for MG_KIND_COMPETITIVE (use mg_gen_obs)");
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_step: call mg_reset (or mg_set_state) first");
@@ -3564,7 +3570,7 @@ int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const u
               void *stream) {
     if (!h) return MG_EINVAL;
     if (num_steps < 1) return fail(h, MG_EINVAL, "mg_step_n: num_steps must be positive");
-    if (num_steps > 1 && h->lds_multi && h->multi_enabled && !(out && out->onehot_dev)) {
+    if (num_steps > 1 && h->lds_multi && h->multi_enabled && !(out && (out->onehot_dev || out->rows_dev || out->reward64_dev))) {
         // ONE launch takes all the steps: header blocks and grids stay in LDS in between, per step only the
         // actions come in and the observations, rewards and flags go out
         if (!actions_dev) return fail(h, MG_EINVAL, "mg_step_n: actions_dev is null");
@@ -3597,6 +3603,8 @@ int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const u
             o.reward_dev = out->reward_dev ? out->reward_dev + t * per : nullptr;
             o.terminated_dev = out->terminated_dev ? out->terminated_dev + t * per : nullptr;
             o.truncated_dev = out->truncated_dev ? out->truncated_dev + t * per : nullptr;
+            o.rows_dev = out->rows_dev ? out->rows_dev + t * per * 8 : nullptr;
+            o.reward64_dev = out->reward64_dev ? out->reward64_dev + t * per : nullptr;
         }
         const int rc = mg_step(h, actions_dev ? actions_dev + t * per : nullptr, order_dev ? order_dev + t * per : nullptr,
                                out ? &o : nullptr, stream);
@@ -3642,6 +3650,8 @@ int mg_step_shards(const MgHandle *shards, int32_t num_shards, const uint8_t *ac
             o.reward_dev = out->reward_dev ? out->reward_dev + at : nullptr;
             o.terminated_dev = out->terminated_dev ? out->terminated_dev + at : nullptr;
             o.truncated_dev = out->truncated_dev ? out->truncated_dev + at : nullptr;
+            o.rows_dev = out->rows_dev ? out->rows_dev + at * 8 : nullptr;
+            o.reward64_dev = out->reward64_dev ? out->reward64_dev + at : nullptr;
         }
         const int rc = mg_step(shards[k], actions_dev + at, order_dev ? order_dev + at : nullptr, out ? &o : nullptr,
                                streams ? streams[k] : nullptr);
@@ -3657,7 +3667,7 @@ int mg_step_shards(const MgHandle *shards, int32_t num_shards, const uint8_t *ac
 int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
     if (!h) return MG_EINVAL;
     if (!h->reset_done) return fail(h, MG_ESTATE, "mg_gen_obs: call mg_reset (or mg_set_state) first");
-    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_gen_obs: onehot_dev must be 8-byte aligned");
+    if (!out_ok(out)) return fail(h, MG_EINVAL, "mg_gen_obs: onehot_dev, rows_dev and reward64_dev must be 8-byte aligned");
     MG_HIP(h, hipSetDevice(h->cfg.device));
     KParams kp = h->kp;
     set_out(kp, out, h->cfg.view_size, h->force_stream);
@@ -3667,7 +3677,7 @@ int mg_gen_obs(MgHandle h, const MgOut *out, void *stream) {
 int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint8_t *agents_dev, const MgOut *out,
                         void *stream) {
     if (!cfg || !grid_dev || !agents_dev || !out) return fail(nullptr, MG_EINVAL, "mg_gen_obs_of_state: null argument");
-    if (!out_ok(out)) return fail(nullptr, MG_EINVAL, "mg_gen_obs_of_state: onehot_dev must be 8-byte aligned");
+    if (!out_ok(out)) return fail(nullptr, MG_EINVAL, "mg_gen_obs_of_state: onehot_dev, rows_dev and reward64_dev must be 8-byte aligned");
     MgConfig c = *cfg;  // only the geometry, the view and see_through_walls matter for an observation
     c.kind = MG_KIND_EMPTY;
     c.autoreset = MG_AUTORESET_NONE;
@@ -3732,8 +3742,8 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
         MG_HIP(h, hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, st));
         MG_HIP(h, hipStreamSynchronize(st));
         if (bad)
-            return fail(h, MG_EINVAL, "mg_set_state: %d cells or agent rows exceed type<16, color<16, state<16, dir<4; "
-                        "nothing was changed", bad);
+            return fail(h, MG_EINVAL, "mg_set_state: %d cells or agent rows exceed type<16, color<16, state<16, dir<4 or "
+                        "name a position outside the grid; nothing was changed", bad);
     }
     hipLaunchKernelGGL(mg_set_state_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), h->kp,
                        grid_dev, agents_dev, meta_dev, steps_dev, flags_dev);
@@ -3746,13 +3756,13 @@ int mg_set_state(MgHandle h, const uint8_t *grid_dev, const uint8_t *agents_dev,
     return MG_OK;
 }
 
-#ifdef MGRID_EXPERIMENT
+MG_EXP(
 int mg_dbg_buffer(MgHandle h, void *buf_dev, int *num_tiles) {
     h->kp.dbg_buf = static_cast<unsigned long long *>(buf_dev);
     if (num_tiles) *num_tiles = h->num_tiles;
     return MG_OK;
 }
-#endif
+)
 
 int mg_agents_mask(MgHandle h, uint8_t *mask_dev, uint8_t *done_dev, void *stream) {
     if (!h) return MG_EINVAL;

@@ -13,7 +13,6 @@ multigrid/rllib/__init__.py:47-76 and multigrid/pettingzoo/__init__.py:35-70 by 
 """
 from __future__ import annotations
 
-import ctypes
 from collections import defaultdict
 from typing import Any, Dict, Optional
 
@@ -82,30 +81,32 @@ class MultiGridEnv:
         self.num_agents = self.spec["num_agents"]
         self.max_steps = self.spec["max_steps"]
         self.width, self.height = self.spec["width"], self.spec["height"]
-        # Everything a step returns lives in ONE device block (the launch's outputs are views into it) that comes
-        # back with one copy into pinned host memory; actions and agent order go up as one pinned block too: a
-        # step is one upload, one launch, one download and one wait.
+        # Everything a step returns lives in ONE device block (the launch's outputs are views into it, the agent rows
+        # of the state it leaves and the rewards as doubles among them) that comes back with one copy into pinned host
+        # memory; actions and agent order go up as one pinned block too: a step is one upload, one launch, one
+        # download and one wait.
         a, v = self.num_agents, self.spec["view_size"]
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         n_img = a * v * v * 3
         self._off = dict(image=0, direction=n_img, terminated=n_img + a, truncated=n_img + 2 * a,
-                         reward=(n_img + 3 * a + 3) // 4 * 4)
-        self._off["rows"] = self._off["reward"] + 4 * a  # agent rows of the post-step state, 8 bytes per agent
+                         reward=(n_img + 3 * a + 7) // 8 * 8)  # doubles, 8-byte aligned
+        self._off["rows"] = self._off["reward"] + 8 * a  # agent rows of the post-step state, 8 bytes per agent
         total = self._off["rows"] + 8 * a
         self._out_dev = torch.zeros(total, dtype=torch.uint8, device=dev)
         self._out_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
         self._out_np = self._out_host.numpy()
         o, blk = self._off, self._out_dev
         packed = StepOutput(image=blk[:n_img].view(1, a, v, v, 3), direction=blk[o["direction"]:o["direction"] + a].view(1, a),
-                            reward=blk[o["reward"]:o["rows"]].view(torch.float32).view(1, a),
+                            reward=None,
                             terminated=blk[o["terminated"]:o["terminated"] + a].view(1, a),
-                            truncated=blk[o["truncated"]:o["truncated"] + a].view(1, a))
+                            truncated=blk[o["truncated"]:o["truncated"] + a].view(1, a),
+                            rows=blk[o["rows"]:].view(1, a, 8),
+                            reward64=blk[o["reward"]:o["rows"]].view(torch.float64).view(1, a))
         self._in_host = torch.zeros((2, 1, a), dtype=torch.uint8).pin_memory()
         self._in_np = self._in_host.numpy()
         self._in_dev = torch.zeros((2, 1, a), dtype=torch.uint8, device=dev)
         self._sim = BatchedMultiGrid(self.spec, 1, device=dev, autoreset=_lib.AUTORESET_NONE, out=packed)
         self._layout0 = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._rows_ptr = ctypes.c_void_p(blk[o["rows"]:].data_ptr())
         # RandomMixin keeps the generator that existed at construction time (multigrid/base.py:153);
         # gym.Env.np_random is the same object until reset(seed) replaces it.
         self._np_random = layout_rng if layout_rng is not None else np.random.default_rng()
@@ -162,17 +163,9 @@ class MultiGridEnv:
         # base.py:457-461
         order = np.zeros(1, dtype=np.uint8) if a == 1 else self._np_random.random(size=a).argsort()
         got = self._launch_step(acts, order)
-        rew = got["reward"].astype(np.float64)
-        # The device returns float32.  Every reward of a step is a whole number of _reward() values
-        # (multigrid/base.py:655-659; LockedHallway adds one per door, locked_hallway.py:207-211), so the
-        # reference's double is recomputed here from the step count and that number.
-        unit = 1 - 0.9 * (self.step_count / self.max_steps)
-        if unit != 0:
-            for i in np.nonzero(rew)[0]:
-                total = 0.0
-                for _ in range(int(round(rew[i] / unit))):
-                    total += unit
-                rew[i] = total
+        # the doubles _reward() computes (multigrid/base.py:655-659; LockedHallway adds one per door,
+        # locked_hallway.py:207-211), worked out on the device in the reference's order of operations
+        rew = got["reward"]
         term, trunc = got["terminated"].astype(bool), got["truncated"].astype(bool)
         rewards = {i: (float(rew[i]) if rew[i] != 0 else 0) for i in range(a)}
         terminations = {i: np.bool_(term[i]) for i in range(a)}
@@ -210,9 +203,7 @@ class MultiGridEnv:
     def _fetch(self):
         """The packed output block of the last launch as host arrays (copies: the pinned block is reused)."""
         stream = torch.cuda.current_stream(self._out_dev.device)
-        # the agent rows of the state the launch left behind travel in the same block (is_done, agent_states)
-        _lib.check(_lib.lib().mg_get_state(self._sim._h, None, self._rows_ptr, None, None, None,
-                                           ctypes.c_void_p(stream.cuda_stream)), self._sim._h)
+        # (the agent rows of the state the launch left behind - is_done, agent_states - travel in the same block)
         self._out_host.copy_(self._out_dev, non_blocking=True)
         stream.synchronize()
         a, v, o, h = self.num_agents, self.spec["view_size"], self._off, self._out_np
@@ -221,7 +212,7 @@ class MultiGridEnv:
                     direction=h[o["direction"]:o["direction"] + a].astype(np.int64),
                     terminated=h[o["terminated"]:o["terminated"] + a].copy(),
                     truncated=h[o["truncated"]:o["truncated"] + a].copy(),
-                    reward=h[o["reward"]:o["reward"] + 4 * a].view(np.float32).copy())
+                    reward=h[o["reward"]:o["reward"] + 8 * a].view(np.float64).copy())
 
     def _obs_dict(self, got):
         img, direction = got["image"], got["direction"]
@@ -295,7 +286,7 @@ class CompetativeRedBlueDoorEnv(MultiGridEnv):
                 order.append(k)
         order += [k for k in range(a) if k not in order]
         got = self._launch_step(acts[0], order)
-        rew = got["reward"].astype(np.float64)  # float32 on the device
+        rew = got["reward"]  # doubles, accumulated on the device as the reference accumulates them
         term, trunc = got["terminated"].astype(bool), got["truncated"].astype(bool)
         obs = self._format_obs(self._obs_dict(got))
         if self.training_scheme == "CTCE":  # :346-368

@@ -130,12 +130,16 @@ class StreamShardedMultiGrid:
         afterwards sees the outputs.  With both (the default) this is ``BatchedMultiGrid.step`` in S pieces, correct
         for any caller and no faster.  The slices run ahead of each other only with ``join=False``: the caller then
         consumes slice k on ``streams[k]`` (or after ``join(k)``), and may pass ``fork=False`` when the actions
-        are known to be complete."""
+        are known to be complete.  ``fork=False`` is honoured only for inputs that are used as they are (contiguous
+        uint8 tensors on this device): anything converted or copied here is produced on the current stream, which
+        the slices then have to wait for, so such a call forks regardless."""
         sh0 = self.shards[0]
-        act = sh0._dev_u8(actions, (self.E, self.A)) if not (
-            isinstance(actions, torch.Tensor) and actions.dtype == torch.uint8 and actions.device == self.device and
-            actions.is_contiguous() and actions.shape == (self.E, self.A)) else actions
-        od = None if order is None else sh0._dev_u8(order, (self.E, self.A))
+        ready = lambda x: (isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.device == self.device and
+                           x.is_contiguous() and x.shape == (self.E, self.A))
+        act = actions if ready(actions) else sh0._dev_u8(actions, (self.E, self.A))
+        od = None if order is None else (order if ready(order) else sh0._dev_u8(order, (self.E, self.A)))
+        if act is not actions or (od is not None and od is not order):
+            fork = True  # a temporary made on the current stream
         if fork:
             self.fork()
             for s in self.streams:  # the allocator must not hand these out again before the slices have read them
@@ -155,14 +159,27 @@ class StreamShardedMultiGrid:
         a contiguous copy of its part - or a list with one contiguous ``[T, E_k, A]`` tensor per slice.  Returns one
         ``StepOutput`` per slice with ``[T, E_k, ...]`` tensors (``bounds[k]`` names the slice's environments):
         the slices' results are not interleaved in memory, their consumers work per slice anyway."""
+        made = []  # anything converted or copied here is produced on the current stream
+
         def parts(x):
             if x is None:
                 return [None] * len(self.shards)
             if isinstance(x, (list, tuple)):
-                return list(x)
+                out = []
+                for (lo, hi), t in zip(self.bounds, x):
+                    ok = (isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and t.device == self.device and
+                          t.is_contiguous())
+                    out.append(t if ok else torch.as_tensor(t).to(device=self.device, dtype=torch.uint8).contiguous())
+                    if not ok:
+                        made.append(out[-1])
+                return out
             x = torch.as_tensor(x).to(device=self.device, dtype=torch.uint8)
-            return [x[:, lo:hi].contiguous() for lo, hi in self.bounds]
-        acts, ords = parts(actions), parts(order)  # (copies, if any, are made on the current stream)
+            cut = [x[:, lo:hi].contiguous() for lo, hi in self.bounds]
+            made.extend(cut)
+            return cut
+        acts, ords = parts(actions), parts(order)
+        if made:
+            fork = True  # the slices' streams must wait for those copies, whatever the caller knows about its inputs
         if fork:
             self.fork()
         res = []

@@ -333,6 +333,7 @@ def test_explicit_tile_shapes(case, tile, monkeypatch):
     """Tile shapes the size heuristic does not pick for small batches, among them sub-tiles whose grids
     exceed the 8 KiB the prefetch registers hold (wide2)."""
     table = dict(CASES, wide2=("MultiGrid-Empty-16x16-v0", 2, dict(max_steps=40)))
+    monkeypatch.setenv("MGRID_TUNING", "1")
     monkeypatch.setenv("MGRID_TILE", tile)
     e = 1111
     spec, pool, env, ora = make(case, e, table=table, autoreset=2)
@@ -366,6 +367,7 @@ def test_staging_widths_and_act_forms(case, lanes, stage, monkeypatch):
     """The step kernel's variants that the library otherwise picks by batch size and kind: images staged 16, 32 or 64
     agents at a time (MGRID_STAGE), and the act phase started with one lane per agent or per environment
     (MGRID_LANES_ACT).  Same contract as everywhere: bit-exact against the C oracle, same-step auto-reset."""
+    monkeypatch.setenv("MGRID_TUNING", "1")
     monkeypatch.setenv("MGRID_STAGE", stage)
     if lanes is not None:
         monkeypatch.setenv("MGRID_LANES_ACT", lanes)
@@ -451,3 +453,50 @@ def test_two_shards_equal_one_batch(case):
     assert sw[0] > 0 and (sw[:5] == sl[:5] + sh[:5]).all() and sw[5] == sl[5] == sh[5] == 70
     for x in (whole, lo, hi):
         x.close()
+
+
+@pytest.mark.parametrize("case", ["cfg3", "cfg4", "joint8_empty", "big10", "odd5"])
+def test_agent_rows_and_double_rewards_from_the_step_launch(case):
+    """MgOut.rows_dev / reward64_dev: the agent rows of the state a step (reset, gen_obs) leaves and the rewards as
+    doubles, written by the same launch - rows against mg_get_state and the oracle's agent array, rewards EQUAL to the
+    oracle's doubles (multigrid/base.py:655-659 in the reference's order of operations), not merely close."""
+    import torch
+    from multigrid_amd.batched import StepOutput
+    e = 2100
+    spec, pool, env, ora = make(case, e)
+    a = spec["num_agents"]
+    out = StepOutput(image=env.out.image, direction=env.out.direction, reward=env.out.reward, terminated=env.out.terminated,
+                     truncated=env.out.truncated, rows=torch.full((e, a, 8), 77, dtype=torch.uint8, device="cuda:0"),
+                     reward64=torch.full((e, a), -5.0, dtype=torch.float64, device="cuda:0"))
+    rng = np.random.default_rng(2)
+    idx = rng.integers(0, len(pool[0]), size=e)
+    env.reset(layout_idx=idx, out=out)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.rows.cpu().numpy(), ora.agents, err_msg="rows after reset")
+    assert (out.reward64 == -5.0).all()  # a reset writes no rewards
+    paid = 0
+    for t in range(60):
+        actions, order = rand_inputs(rng, e, a)
+        env.step(actions, order, out=out)
+        res = ora.step(actions, order)
+        compare(out, res, f"{case} step {t}")
+        np.testing.assert_array_equal(out.rows.cpu().numpy(), ora.agents, err_msg=f"{case} rows step {t}")
+        np.testing.assert_array_equal(out.reward64.cpu().numpy(), res[2], err_msg=f"{case} double rewards step {t}")
+        paid += int((res[2] != 0).sum())
+    assert paid > 0 or case != "joint8_empty"  # (the small Empty rooms pay often)
+    out.rows.fill_(0)
+    env.gen_obs(out=out)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.rows.cpu().numpy(), env.get_state()["agents"].cpu().numpy())
+    # with these outputs mg_step_n takes one launch per step and still fills every slice
+    T = 3
+    acts = rng.integers(0, 7, size=(T, e, a)).astype(np.uint8)
+    many = env.step_n(acts, out=StepOutput(
+        image=None, direction=None, reward=torch.zeros((T, e, a), dtype=torch.float32, device="cuda:0"),
+        terminated=None, truncated=None, rows=torch.zeros((T, e, a, 8), dtype=torch.uint8, device="cuda:0"),
+        reward64=torch.zeros((T, e, a), dtype=torch.float64, device="cuda:0")))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(many.rows[-1].cpu().numpy(), env.get_state()["agents"].cpu().numpy())
+    np.testing.assert_allclose(many.reward64.cpu().numpy(), many.reward.cpu().numpy().astype(np.float64), rtol=0, atol=1e-6)
+    env.close()

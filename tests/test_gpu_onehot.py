@@ -159,6 +159,7 @@ def test_streaming_stores_either_way(case, stream, monkeypatch):
     from multigrid_amd.batched import BatchedMultiGrid
     from oracle.coracle import BatchOracle
 
+    monkeypatch.setenv("MGRID_TUNING", "1")
     monkeypatch.setenv("MGRID_STREAM", stream)
     name, agents, extra = CASES[case]
     spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **extra))

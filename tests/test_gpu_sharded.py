@@ -269,3 +269,35 @@ def test_shards_of_competitive_environments():
         assert torch.equal(st_w[k], st_c[k]), k
     whole.close()
     cut.close()
+
+
+def test_unforked_steps_with_inputs_that_need_a_copy():
+    """fork=False is only honoured for inputs used as they are.  Host arrays (copied to the device on the current
+    stream) and a whole-batch [T, E, A] tensor for step_n (cut into per-slice copies there) make the call wait for
+    those copies whatever the caller said; results equal one handle's."""
+    import torch
+    spec, pool, whole, cut = make_pair("cfg4", 1900, 2, autoreset=1, seed=9)
+    a, e = spec["num_agents"], 1900
+    whole.reset()
+    cut.reset()
+    rng = np.random.default_rng(4)
+    for t in range(25):
+        acts = rng.integers(0, 7, size=(e, a)).astype(np.uint8)       # host array: uploaded inside step()
+        order = np.argsort(rng.random((e, a)), axis=1).astype(np.uint8)
+        w = whole.step(acts, order)
+        c = cut.step(acts, order, fork=False, join=False)
+        cut.join()
+        torch.cuda.synchronize()
+        for f in FIELDS:
+            assert torch.equal(getattr(w, f), getattr(c, f)), f"step {t} {f}"
+    T = 6
+    acts = torch.from_numpy(rng.integers(0, 7, size=(T, e, a)).astype(np.uint8)).cuda()
+    wn = whole.step_n(acts)
+    parts = cut.step_n(acts, fork=False, join=False)  # whole-batch tensor: per-slice copies are made inside
+    cut.join()
+    torch.cuda.synchronize()
+    for (lo, hi), o in zip(cut.bounds, parts):
+        for f in FIELDS:
+            assert torch.equal(getattr(wn, f)[:, lo:hi], getattr(o, f)), f"step_n {f}"
+    whole.close()
+    cut.close()

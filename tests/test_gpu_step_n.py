@@ -77,12 +77,14 @@ def test_multi_step_launch_with_device_order(case, mode):
 @pytest.mark.parametrize("case,tile", [("cfg4", "8,4"), ("cfg2", "20,2"), ("cfg5", "2,3"), ("odd3", "7,3")])
 def test_multi_step_launch_with_several_sub_tiles(case, tile, monkeypatch):
     """Tiles of several sub-tiles keep ALL their grids in LDS in the multi-step kernel."""
+    monkeypatch.setenv("MGRID_TUNING", "1")
     monkeypatch.setenv("MGRID_TILE", tile)
     run_case(case, 1, 9, 1111)
 
 
 def test_step_n_without_the_multi_step_kernel(monkeypatch):
     """The per-step fallback (forced here; also taken for one-hot outputs) gives the same slices."""
+    monkeypatch.setenv("MGRID_TUNING", "1")
     monkeypatch.setenv("MGRID_MULTI_STEP", "0")
     run_case("cfg4", 1, 9, 900)
 

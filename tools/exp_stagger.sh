@@ -2,6 +2,7 @@
 # Diagnostic build only (tools/build_exp.sh): staggered tile starts (MGRID_DBG bit 6, see the kernel) against the same
 # binary without them, one box, one call.
 set -e
+export MGRID_TUNING=1  # the library reads its tuning switches only with this opt-in
 export MGRID_LIB=tools/libmgrid_exp.so
 run() {  # label, dbg, bench arguments
     local label=$1 dbg=$2; shift 2

@@ -1,6 +1,7 @@
 """Per-phase clock stamps from the diagnostic build (tools/libmgrid_exp.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MGRID_TUNING", "1")  # MGRID_DBG and MGRID_TILE are read only with this opt-in
 os.environ["MGRID_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmgrid_exp.so")
 import numpy as np, torch
 from multigrid_amd import _lib, envs, layouts

@@ -1,5 +1,6 @@
 """Tile-shape sweep: time mg_step for several (NE, G) shapes per configuration (MGRID_TILE override)."""
 import os, sys
+os.environ["MGRID_TUNING"] = "1"  # the library reads MGRID_TILE only with this opt-in
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multigrid_amd import envs, layouts
