@@ -133,7 +133,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out_path: 
                 r = report[k]
                 print(f"  {r['vgpr_count']:3d} vgpr {r['sgpr_count']:3d} sgpr  spills {r['sgpr_spill_count']:3d} s / "
                       f"{r['vgpr_spill_count']:3d} v  scratch {r['private_segment_fixed_size']:4d} B  {k}")
-        if spilling:
+        if spilling and os.environ.get("MGRID_ALLOW_SPILLS") != "1":  # (the switch is for work in progress only)
             raise RuntimeError(f"{len(spilling)} instantiation(s) of the tile kernel spill vector registers to scratch "
                                f"memory, e.g. {spilling[0]}: {report[spilling[0]]}")
         # a new inode, renamed into place: processes that have the old library mapped keep the old file

@@ -45,6 +45,9 @@
 #include <mutex>
 
 #include "mgrid.h"
+// Rewards are doubles worked out in the reference's order of operations (multigrid/base.py:655-659 and the hooks'
+// `+=`), every operation rounded on its own as Python rounds it: no fused multiply-add anywhere in this file.
+#pragma clang fp contract(off)
 #include "mgrid_experiment.h"  // MG_EXP / MG_STAMP / MG_TICK: empty unless this is a diagnostic build
 
 // Device memory of mg_gen_obs_of_state(), the one entry point that must not allocate: the packed copy of the
@@ -82,16 +85,12 @@ constexpr int MODE_STEP = 0, MODE_OBS = 1, MODE_RESET = 2;
 #ifndef MG_STAGE_LANES
 #define MG_STAGE_LANES 32
 #endif
-// From this many agents per environment on, the act phase always starts with one lane per agent (act_lanes()).
-// Below, it does so for Empty and RedBlueDoors environments, whose agents seldom get in each other's way (their
-// steps are then finished by act_lanes() alone in nearly every wavefront: measured 7 % faster on 4096 x 2 agents of
-// RedBlueDoors-8x8); BlockedUnlockPickup and LockedHallway with 2-4 agents in small rooms leave an agent for the
-// in-order replay in most wavefronts, which then pay for both forms (measured 13 % slower), so they go straight
-// to the in-order form (one lane per environment), as single-agent environments do.
-#ifndef MG_PARALLEL_ACT_MIN_AGENTS
-#define MG_PARALLEL_ACT_MIN_AGENTS 6
+// From this many agents per environment on (up to 8), environments whose agents may not overlap take the cell-table
+// variant of the act phase (act_lanes<true>): most of their steps have agents to compare.
+#ifndef MG_CROWD_MIN_AGENTS
+#define MG_CROWD_MIN_AGENTS 6
 #endif
-constexpr int PARALLEL_ACT_MIN_AGENTS = MG_PARALLEL_ACT_MIN_AGENTS;
+constexpr int CROWD_MIN_AGENTS = MG_CROWD_MIN_AGENTS;
 #ifndef MG_COPY_BATCH
 #define MG_COPY_BATCH 5
 #endif
@@ -149,7 +148,6 @@ struct KParams {
     __host__ __device__ bool comp() const { return (bits >> 23) & 1; }
     __host__ __device__ bool death_match() const { return (bits >> 24) & 1; }
     __host__ __device__ bool per_agent() const { return (bits >> 25) & 1; }  // dtde_step rather than ctce_step
-    __host__ __device__ bool lanes_act() const { return (bits >> 26) & 1; }  // the act phase starts with one lane per agent
     int max_steps;
     int E, HS, HFC, GS, num_layouts;  // HFC: offset of the front cells inside a header block
     int GP;  // distance between two environments' grids in LDS: GS + 16 (a tuning build may widen it)
@@ -335,13 +333,6 @@ enum : uint32_t {
     EV_TRY_FWD = 4096u, EV_TRY_DROP = 8192u, EV_UNSTABLE = 16384u,
 };
 
-// An environment's word in the LDS `flag` array between act_lanes() and act_env*(): bits 16-23 number
-// of cells written so far, and
-constexpr uint32_t ACT_REPLAY = 1u << 8;     // some agents are left to act, in order; `tout` marks them
-constexpr uint32_t ACT_REPLAY_ALL = 1u << 9; // act_lanes() did not run: every agent is left to act
-constexpr uint32_t ACT_RESYNC = 1u << 24;    // a blue-door toggle re-synced cell and object
-constexpr uint32_t ACT_FINISHED = 1u << 25;  // act_lanes() has finished the whole step
-
 struct ActEval {
     uint2 r;        // the agent's row after the action
     uint32_t fxy;   // position in front, x | y << 8
@@ -425,297 +416,8 @@ __device__ __forceinline__ void finish_action(const KParams &p, ActEval &e, uint
     if (dr || (e.bits & (EV_PK | EV_UNLOCK | EV_FLIP | EV_BOX))) e.bits |= EV_WRITE;
 }
 
-struct EnvView {
-    uint8_t *rows;        // agent rows in LDS
-    const uint16_t *fcv;  // front cells as of the start of the step (header block)
-    uint32_t *log;        // cells written during this step: index | value << 16, in order
-    int nlog;
-    uint8_t *rewm;        // [A] reward multipliers
-    uint8_t *tout;        // [A] terminated as returned to the caller
-    uint32_t flags;
-    int A;
-};
-
-// every agent counts, terminated ones included: multigrid/base.py:485,512
-__device__ __forceinline__ bool agent_at(const EnvView &ev, uint32_t xy) {
-    bool hit = false;
-    for (int k = 0; k < ev.A; ++k) hit |= *reinterpret_cast<const uint16_t *>(ev.rows + 8 * k) == xy;
-    return hit;
-}
-
-// current value of grid cell `ci`, given its value at the start of the step
-__device__ __forceinline__ uint32_t cell_now(const EnvView &ev, uint32_t ci, uint32_t at_start) {
-    uint32_t w = at_start;
-    for (int j = 0; j < ev.nlog; ++j) {
-        const uint32_t e = ev.log[j];
-        if ((e & 0xFFFF) == ci) w = e >> 16;
-    }
-    return w;
-}
-
-// on_success, multigrid/base.py:535-562, as called from the environment hooks (a non-empty
-// terminations dict).  The reward _reward() is the same number R for every call within one step,
-// so "rewards[k] = R" is kept as a multiplier 1 and LockedHallway's "+= R" as multiplier + 1.
-__device__ __forceinline__ void hook_success(const KParams &p, EnvView &ev, int i) {
-    if (p.succ_any()) {
-        for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
-    } else {
-        ev.rows[8 * i + R_TERM] = 1;
-        ev.tout[i] = 1;
-    }
-    if (p.joint())
-        for (int k = 0; k < ev.A; ++k) ev.rewm[k] = 1;
-    else
-        ev.rewm[i] = 1;
-}
-
-// on_failure, multigrid/base.py:564-585, as called from the environment hooks
-__device__ __forceinline__ void hook_failure(const KParams &p, EnvView &ev, int i) {
-    if (p.fail_any()) {
-        for (int k = 0; k < ev.A; ++k) { ev.rows[8 * k + R_TERM] = 1; ev.tout[k] = 1; }
-    } else {
-        ev.rows[8 * i + R_TERM] = 1;
-        ev.tout[i] = 1;
-    }
-}
-
-// MultiGridEnv.step up to (not including) gen_obs, then the subclass hook:
-// multigrid/base.py:395-396,440-533 and redbluedoors.py:176-185,
-// blockedunlockpickup.py:165-167, locked_hallway.py:200-215.
-//
-// The grid itself is not in LDS here.  Each agent acts once per step and only its own action
-// moves or turns it, so the cell in front of every agent is known before the first action: those
-// A cells (plus the two RedBlueDoors doors) travel with the header block - the observation pass of
-// the previous launch left them there.  Cells written during the step go to a short log that
-// later readers of the same cell consult.
-__device__ void act_env(const KParams &p, uint8_t *lds, int slot, int env) {
-    const int A = p.A();
-    uint8_t *h = lds + p.o.hdr + slot * p.HP;
-    EnvView ev;
-    ev.A = A;
-    ev.rows = h + H_ROWS;
-    ev.fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
-    ev.log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
-    ev.nlog = 0;
-    ev.rewm = lds + p.o.rewm + slot * A;
-    ev.tout = lds + p.o.tout + slot * A;
-    uint8_t *oterm = lds + p.o.oterm + slot * A;
-    const uint8_t *actb = lds + p.o.act + slot * A;
-    uint8_t *ordb = lds + p.o.ord + slot * A;
-
-    if (*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot) & ACT_FINISHED) return;
-    const uint4 h0 = *reinterpret_cast<const uint4 *>(h);
-    const int step = static_cast<int>(h0.x) + 1;  // base.py:395
-    *reinterpret_cast<int *>(h + H_STEP) = step;
-    ev.flags = h0.z & 0xFF;
-    const uint32_t was_over = ev.flags & FLAG_OVER;
-    const uint32_t blue_xy = h0.w >> 16;
-    const bool rbd = p.kind() == MG_KIND_REDBLUEDOORS;
-    reinterpret_cast<double *>(lds + p.o.R)[slot] = step_reward(p, step);
-
-    // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
-    const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
-    if (fl0 & (ACT_REPLAY | ACT_REPLAY_ALL)) {
-        // some agents' actions touch each other: those act one by one in the order of base.py:457-464
-        // (`tout` marks them; the others have acted in act_lanes() already)
-        if (p.order == nullptr) {
-            const uint32_t key = order_key(p, env, h0.y, step);
-            for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
-            uint32_t word = 0;
-            for (int k = A - 1, f = 0; k > 0; --k, ++f) {
-                const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
-                const uint8_t t = ordb[k];
-                ordb[k] = ordb[j];
-                ordb[j] = t;
-            }
-        }
-
-        const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
-        if (everyone)
-            for (int k = 0; k < A; ++k) ev.rewm[k] = 0;  // base.py:454
-        else
-            ev.nlog = (fl0 >> 16) & 0xFF;
-        if (fl0 & ACT_RESYNC) ev.flags &= ~FLAG_STALE;
-
-        for (int n = 0; n < A; ++n) {  // base.py:464
-            const int i = ordb[n];
-            if (i >= A) continue;
-            if (!everyone && ev.tout[i] == 0) continue;
-            uint8_t *a = ev.rows + 8 * i;
-            uint2 r = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
-            const uint32_t w0 = ev.fcv[i];
-            if ((r.x >> 24) & 0xFF) continue;  // base.py:467
-            const int act = actb[i];
-            const int dir = (r.x >> 16) & 0xFF;
-            if (act == ACT_LEFT || act == ACT_RIGHT) {  // base.py:471-476
-                a[R_DIR] = static_cast<uint8_t>((dir + (act == ACT_LEFT ? 3 : 1)) & 3);
-                continue;
-            }
-            if (act >= ACT_DONE) continue;  // base.py:527-528
-            const uint32_t ci = front_index(p, r.x);
-            if (ci == FC_NONE) continue;  // front cell outside the grid: cannot happen inside border walls
-            const uint32_t fxy = front_xy(r.x);  // agent.py:153-160
-            const uint32_t w = cell_now(ev, ci, w0);
-            const int t = w & 15, s = (w >> 4) & 15, c = (w >> 8) & 127;
-            const int ct = r.y & 0xFF, cc = (r.y >> 8) & 0xFF;
-            const bool blue = rbd && fxy == blue_xy;
-            // state of the world OBJECT: equals the cell except for the blue door re-closed by
-            // redbluedoors.py:185 without a grid.update
-            const int so = (blue && (ev.flags & FLAG_STALE)) ? S_CLOSED : s;
-            bool write = false, moved = false;
-            uint32_t nv = 0;
-            if (act == ACT_FORWARD) {  // base.py:479-494
-                const bool can_overlap = t == T_EMPTY || t == T_GOAL || t == T_FLOOR || t == T_LAVA ||
-                                         (t == T_DOOR && so == S_OPEN);
-                if (can_overlap && (p.overlap() || !agent_at(ev, fxy))) {
-                    r.x = (r.x & 0xFFFF0000u) | fxy;
-                    moved = true;
-                    // on_success / on_failure with the empty terminations dict of base.py:492,494:
-                    // mode "any" terminates nobody here, mode "all" terminates this agent
-                    if (t == T_GOAL) {
-                        if (!p.succ_any()) r.x |= 1u << 24;
-                        if (p.joint())
-                            for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
-                        else
-                            ev.rewm[i] = 1;
-                    }
-                    if (t == T_LAVA && !p.fail_any()) r.x |= 1u << 24;
-                }
-            } else if (act == ACT_PICKUP) {  // base.py:497-504
-                if ((t == T_KEY || t == T_BALL || t == T_BOX) && ct == T_EMPTY) {
-                    r.y = (r.y & 0xFF000000u) | static_cast<uint32_t>(t | (c << 8) | (s << 16));
-                    moved = true;
-                    write = true;
-                    nv = CELL_EMPTY;
-                }
-            } else if (act == ACT_DROP) {  // base.py:507-516
-                if (ct != T_EMPTY && t == T_EMPTY && !agent_at(ev, fxy)) {
-                    write = true;
-                    nv = pack_cell(ct, cc, (r.y >> 16) & 0xFF);
-                    r.y = (r.y & 0xFF000000u) | T_EMPTY;
-                    moved = true;
-                }
-            } else {  // toggle, base.py:519-524
-                if (t == T_DOOR) {  // Door.toggle, world_object.py:456-472
-                    if (so == S_LOCKED) {
-                        if (ct == T_KEY && cc == c) {
-                            write = true;
-                            nv = pack_cell(T_DOOR, c, S_OPEN);
-                        }
-                    } else {
-                        write = true;
-                        nv = pack_cell(T_DOOR, c, so == S_OPEN ? S_CLOSED : S_OPEN);
-                        if (blue) ev.flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
-                    }
-                } else if (t == T_BOX) {  // Box.toggle with no contents, world_object.py:653-659
-                    write = true;
-                    nv = CELL_EMPTY;
-                }
-            }
-            if (moved) *reinterpret_cast<uint2 *>(a) = r;
-            if (write) ev.log[ev.nlog++] = ci | (nv << 16);
-        }
-    } else {
-        // independent actions: act_lanes() has applied them already
-        ev.nlog = (fl0 >> 16) & 0xFF;
-        if (fl0 & ACT_RESYNC) ev.flags &= ~FLAG_STALE;
-    }
-    if (p.joint()) {  // base.py:558-559: a reward paid to one is paid to all
-        bool any = false;
-        for (int k = 0; k < A; ++k) any |= ev.rewm[k] != 0;
-        if (any)
-            for (int k = 0; k < A; ++k) ev.rewm[k] = 1;
-    }
-
-    // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
-    for (int k = 0; k < A; ++k) {
-        const uint8_t t = ev.rows[8 * k + R_TERM];
-        ev.tout[k] = t;
-        oterm[k] = t;
-    }
-    const bool trunc = step >= p.max_steps;
-
-    // subclass hooks run on the returned dicts, agents in index order.  An agent whose action was
-    // "toggle" has neither moved nor turned, so its header entry still names the cell in front of it.
-    if (rbd) {  // redbluedoors.py:176-185
-        for (int i = 0; i < A; ++i) {
-            const int act = actb[i];
-            if (act != ACT_TOGGLE) continue;
-            if (front_xy(*reinterpret_cast<const uint32_t *>(ev.rows + 8 * i)) != blue_xy) continue;
-            const uint32_t wb = cell_now(ev, (blue_xy & 0xFF) * p.H() + (blue_xy >> 8), ev.fcv[A + 1]);
-            if ((wb & 15) != T_DOOR) continue;
-            const int so = (ev.flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
-            if (so != S_OPEN) continue;
-            const uint32_t wr = cell_now(ev, ((h0.w >> 0) & 0xFF) * p.H() + ((h0.w >> 8) & 0xFF), ev.fcv[A]);
-            if (((wr >> 4) & 15) == S_OPEN) {
-                hook_success(p, ev, i);
-            } else {
-                hook_failure(p, ev, i);
-                ev.flags |= FLAG_STALE;
-            }
-        }
-    } else if (p.kind() == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
-        for (int i = 0; i < A; ++i)
-            if (ev.rows[8 * i + R_CT] == T_BOX) hook_success(p, ev, i);
-    } else if (p.kind() == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
-        for (int i = 0; i < A; ++i) {
-            const int act = actb[i];
-            if (act != ACT_TOGGLE) continue;
-            const uint32_t ci = front_index(p, *reinterpret_cast<const uint32_t *>(ev.rows + 8 * i));
-            if (ci == FC_NONE) continue;
-            const uint32_t w = cell_now(ev, ci, ev.fcv[i]);
-            if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
-            const uint32_t bit = 1u << ((w >> 8) & 7);
-            if (ev.flags & bit & FLAG_LH_MASK) continue;
-            ev.flags |= bit & FLAG_LH_MASK;
-            if (p.joint())
-                for (int k = 0; k < A; ++k) ev.rewm[k]++;
-            else
-                ev.rewm[i]++;
-        }
-        if (__popc(ev.flags & FLAG_LH_MASK) == p.num_rooms())
-            for (int k = 0; k < A; ++k) ev.tout[k] = 1;
-    }
-
-    bool all_term = true;
-    int paid = 0;
-    for (int k = 0; k < A; ++k) {
-        all_term &= ev.tout[k] != 0;
-        paid += ev.rewm[k];
-    }
-    const bool over = trunc || all_term;
-    if (over) ev.flags |= FLAG_OVER;
-    h[H_FLAGS] = static_cast<uint8_t>(ev.flags);
-
-    uint8_t *fl = lds + p.o.flag + 4 * slot;
-    const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
-    fl[0] = trunc ? 1 : 0;
-    fl[1] = will_reset ? 1 : 0;
-    fl[2] = static_cast<uint8_t>(ev.nlog);
-
-    // episode statistics: touched only when something happened (rare)
-    if (over && !was_over) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
-    }
-    if (paid != 0) {
-        const double R = reinterpret_cast<const double *>(lds + p.o.R)[slot];
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
-                  static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
-    }
-
-    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
-    if (!will_reset) {
-        uint16_t *gg = reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env) * p.GS);
-        for (int j = 0; j < ev.nlog; ++j) {
-            const uint32_t e = ev.log[j];
-            gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
-        }
-    }
-}
-
-// ---- act, up to 8 agents: the same step with per-agent bytes packed into 64-bit registers -------------
+// ---- act, one lane per environment (CompetativeRedBlueDoor steps, up to 8 agents): the reference's sequential
+// handle_actions loop as it stands, per-agent bytes packed into 64-bit registers -------------------------------
 
 __device__ __forceinline__ uint32_t byte_of(uint64_t w, int k) { return static_cast<uint32_t>(w >> (8 * k)) & 0xFF; }
 
@@ -738,8 +440,9 @@ __device__ __forceinline__ void store_bytes(uint8_t *ptr, uint64_t w, int A) {
     for (int k = 0; k < A; ++k) ptr[k] = static_cast<uint8_t>(w >> (8 * k));
 }
 
-// Same contract as act_env; `actw` / `ordw` hold the A action and order bytes (ordw is ignored when
-// the order is drawn on the device).
+// MultiGridEnv.step up to (not including) gen_obs, then the environment's hook, for one environment (`slot` of the
+// tile): multigrid/base.py:395-396,440-533 and competative_red_blue_door.py:319-523.  Same contract as act_lanes();
+// `actw` / `ordw` hold the A action and order bytes (agents act in index order when the caller gives no order).
 template <bool COMP>
 __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env, uint64_t actw, uint64_t ordw) {
     const int A = p.A(), H = p.H();
@@ -749,7 +452,6 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + slot * A;
     const uint64_t ones = 0x0101010101010101ull >> (8 * (8 - A));  // byte k = 1 for k < A
 
-    if (*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot) & ACT_FINISHED) return;
     MG_EXP(
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
     MG_TICK(q0);
@@ -765,14 +467,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     // somebody is paid, everybody else's reward being 0 * R
     double R = COMP ? step_reward(p, step) : 0.0;
 
-    // left by act_lanes(): number of cells written, "blue door re-synced", "agents interact"
-    const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
-    int nlog = (fl0 >> 16) & 0xFF;
+    int nlog = 0;           // cells written so far in this step
     uint64_t termw, rewmw;  // byte k: agent k terminated / reward multiplier
-
-    if (fl0 & (ACT_REPLAY | ACT_REPLAY_ALL)) {
-        // some agents' actions touch each other: those act one by one in the order of base.py:457-464
-        // (`tout` marks them; the others have acted in act_lanes() already)
+    {
         if (p.order == nullptr) {  // see order_key()
             const uint32_t key = order_key(p, env, h0.y, step);
             ordw = 0x0706050403020100ull;
@@ -787,17 +484,13 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             }
         }
         MG_EXP(MG_TICK(q1);)
-        const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
-        const uint64_t setw = everyone ? ones : load_bytes(lds + p.o.tout + slot * A, A);  // byte k: agent k acts here
         termw = 0;
-        rewmw = everyone ? 0ull : load_bytes(lds + p.o.rewm + slot * A, A);  // base.py:454
-        if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
+        rewmw = 0ull;  // base.py:454
 #pragma unroll 1
         for (int k = 0; k < A; ++k) termw |= static_cast<uint64_t>(rows[8 * k + R_TERM]) << (8 * k);
 #pragma unroll 1
         for (int n = 0; n < A; ++n) {  // base.py:464
             const int i = min(static_cast<int>(byte_of(ordw, n)), A - 1);
-            if (byte_of(setw, i) == 0) continue;
             uint8_t *a = rows + 8 * i;
             const uint2 r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
             uint32_t w = fcv[i];
@@ -819,11 +512,6 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             if ((ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
             if (ev.bits & EV_WRITE) log[nlog++] = ev.ci | (ev.nv << 16);
         }
-    } else {
-        // independent actions: act_lanes() has applied them already
-        termw = load_bytes(lds + p.o.oterm + slot * A, A);
-        rewmw = load_bytes(lds + p.o.rewm + slot * A, A);
-        if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
     }
     if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559: a reward paid to one is paid to all
     MG_EXP(MG_TICK(q2);)
@@ -1086,253 +774,29 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     )
 }
 
-// ---- act, one lane per environment, for exactly AC = 2 or 4 agents ---------------------------------------
-//
-// Same contract and the same results as act_env_small<false>(), written for a compile-time number of agents: the
-// environment's agent rows, front cells, actions, order and the step's cell log are read from LDS once, live in
-// registers while the agents take their turns and go back once.  With the count known the per-agent lookups are
-// selects instead of dependent LDS round trips and the hooks unroll; measured, the act phase of 2- and 4-agent
-// environments takes well under half the time of the general form.
-// v[i] for a lane-varying i, as bit selects under the masks m[k] = (i == k ? ~0 : 0).  (Written as a chain of
-// `i == k ? v[k] : r` the compiler turns the selects back into an indexed load, and the arrays into scratch memory.)
-template <int AC>
-__device__ __forceinline__ void pick_masks(uint32_t (&m)[AC], int i) {
-#pragma unroll
-    for (int k = 1; k < AC; ++k) {
-        m[k] = i == k ? ~0u : 0u;
-        asm volatile("" : "+v"(m[k]));  // opaque from here on
-    }
-}
-template <int AC>
-__device__ __forceinline__ uint32_t pick(const uint32_t (&v)[AC], const uint32_t (&m)[AC]) {
-    uint32_t r = v[0];
-#pragma unroll
-    for (int k = 1; k < AC; ++k) r = (v[k] & m[k]) | (r & ~m[k]);
-    return r;
-}
-__device__ __forceinline__ uint32_t byte32(uint32_t w, int k) { return (w >> (8 * k)) & 0xFF; }
-
-template <int AC>
-__device__ __forceinline__ void act_env_fixed(const KParams &p, uint8_t *lds, int slot, int env) {
-    static_assert(AC == 2 || AC == 4, "two or four agents: their bytes fill a 16- or 32-bit word");
-    constexpr uint32_t ones = AC == 4 ? 0x01010101u : 0x0101u;  // byte k = 1 for every agent k
-    const int H = p.H();
-    uint8_t *h = lds + p.o.hdr + slot * p.HP;
-    const uint32_t fl0 = *reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * slot);
-    if (fl0 & ACT_FINISHED) return;
-    auto bytes_at = [&](int off) -> uint32_t {  // the environment's AC bytes of a per-agent byte array
-        if (AC == 4) return *reinterpret_cast<const uint32_t *>(lds + off + 4 * slot);
-        return *reinterpret_cast<const uint16_t *>(lds + off + 2 * slot);
-    };
-    auto bytes_to = [&](int off, uint32_t w) {
-        if (AC == 4) *reinterpret_cast<uint32_t *>(lds + off + 4 * slot) = w;
-        else *reinterpret_cast<uint16_t *>(lds + off + 2 * slot) = static_cast<uint16_t>(w);
-    };
-    // ---- everything the step reads -------------------------------------------------------------------------
-    const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | door positions
-    uint32_t rx[AC], ry[AC];                                // agent rows: x y dir term | ct cc cs color
-#pragma unroll
-    for (int k = 0; k < AC; k += 2) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(h + H_ROWS + 8 * k);
-        rx[k] = v.x; ry[k] = v.y; rx[k + 1] = v.z; ry[k + 1] = v.w;
-    }
-    uint32_t fc[AC + 2];  // cells in front of the agents at the start of the step, then the red and the blue door
-    {
-        const uint4 q = *reinterpret_cast<const uint4 *>(h + p.HFC);  // (HFC + 16 <= HS for 2 and for 4 agents)
-        const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int k = 0; k < AC + 2; ++k) fc[k] = (qw[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-    }
-    const uint32_t actw = bytes_at(p.o.act);
-    uint32_t ordw = p.order ? bytes_at(p.o.ord) : 0u;
-    uint32_t logv[AC];  // cells written during this step: index | value << 16, in order
-    if (AC == 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(lds + p.o.log + 16 * slot);
-        logv[0] = v.x; logv[1] = v.y; logv[AC - 2] = v.z; logv[AC - 1] = v.w;
-    } else {
-        const uint2 v = *reinterpret_cast<const uint2 *>(lds + p.o.log + 8 * slot);
-        logv[0] = v.x; logv[1] = v.y;
-    }
-    const uint32_t lanes_tout = bytes_at(p.o.tout), lanes_rewm = bytes_at(p.o.rewm), lanes_oterm = bytes_at(p.o.oterm);
-
-    const int step = static_cast<int>(h0.x) + 1;  // base.py:395
-    uint32_t flags = h0.z & 0xFF;
-    const uint32_t was_over = flags & FLAG_OVER;
-    const uint32_t red_xy = h0.w & 0xFFFF, blue_xy = h0.w >> 16;
-    int nlog = (fl0 >> 16) & 0xFF;  // left by act_lanes(): number of cells written so far
-    if (fl0 & ACT_RESYNC) flags &= ~FLAG_STALE;
-    uint32_t termw, rewmw;  // byte k: agent k terminated / reward multiplier
-    auto cell_as_of_now = [&](uint32_t ci, uint32_t at_start) {
-        uint32_t w = at_start;
-#pragma unroll
-        for (int j = 0; j < AC; ++j)
-            if (j < nlog && (logv[j] & 0xFFFF) == ci) w = logv[j] >> 16;
-        return w;
-    };
-
-    if (fl0 & (ACT_REPLAY | ACT_REPLAY_ALL)) {
-        // agents left to act one by one in the order of base.py:457-464 (`tout` marks them; the others have acted
-        // in act_lanes() already)
-        if (p.order == nullptr) {  // see order_key()
-            const uint32_t key = order_key(p, env, h0.y, step);
-            ordw = 0x03020100u;
-            uint32_t word = 0;
-#pragma unroll
-            for (int k = AC - 1, f = 0; k > 0; --k, ++f) {
-                const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
-                const uint32_t d = byte32(ordw, k) ^ byte32(ordw, j);
-                ordw ^= (d << (8 * k)) ^ (d << (8 * j));
-            }
-        }
-        const bool everyone = (fl0 & ACT_REPLAY_ALL) != 0;
-        const uint32_t setw = everyone ? ones : lanes_tout;  // byte k: agent k acts here
-        rewmw = everyone ? 0u : lanes_rewm;                   // base.py:454
-        termw = 0;
-#pragma unroll
-        for (int k = 0; k < AC; ++k) termw |= (rx[k] >> 24) << (8 * k);
-#pragma unroll 1
-        for (int n = 0; n < AC; ++n) {  // base.py:464
-            const int i = min(static_cast<int>(byte32(ordw, n)), AC - 1);
-            if (byte32(setw, i) == 0) continue;
-            uint32_t im[AC], fca[AC];
-            pick_masks<AC>(im, i);
-#pragma unroll
-            for (int k = 0; k < AC; ++k) fca[k] = fc[k];
-            const uint2 r0 = make_uint2(pick<AC>(rx, im), pick<AC>(ry, im));
-            const uint32_t w = cell_as_of_now(front_index(p, r0.x), pick<AC>(fca, im));
-            ActEval ev = eval_action(p, r0, w, static_cast<int>(byte32(actw, i)), flags, blue_xy);
-            bool occupied = false;  // base.py:485,512: every agent counts, terminated ones included
-#pragma unroll
-            for (int k = 0; k < AC; ++k) occupied |= (rx[k] & 0xFFFFu) == ev.fxy;
-            finish_action(p, ev, r0, occupied);
-            if (ev.bits & EV_TERM) termw |= 1u << (8 * i);
-            if (ev.bits & EV_GOAL) rewmw = p.joint() ? ones : ((rewmw & ~(0xFFu << (8 * i))) | (1u << (8 * i)));  // base.py:558-562
-            if ((ev.bits & EV_FLIP) && (ev.bits & EV_BLUE)) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
-            const bool alive = (ev.bits & EV_ALIVE) != 0, wr = (ev.bits & EV_WRITE) != 0;
-#pragma unroll
-            for (int k = 0; k < AC; ++k) {
-                if (alive && i == k) { rx[k] = ev.r.x; ry[k] = ev.r.y; }
-                if (wr && nlog == k) logv[k] = ev.ci | (ev.nv << 16);
-            }
-            if (wr) ++nlog;
-        }
-    } else {
-        // independent actions: act_lanes() has applied them already
-        termw = lanes_oterm;
-        rewmw = lanes_rewm;
-    }
-    if (p.joint() && rewmw) rewmw = ones;  // base.py:558-559: a reward paid to one is paid to all
-
-    // what gen_obs sees (base.py:399) and what step returns (base.py:400-402)
-    uint32_t toutw = termw;
-    const bool trunc = step >= p.max_steps;
-
-    // subclass hooks run on the returned dicts, agents in index order.  An agent whose action was "toggle" has
-    // neither moved nor turned, so its front cell of the start of the step is still the cell in front of it.
-    bool term_all = false;   // a hook terminated every agent
-    uint32_t term_some = 0;  // a hook terminated these agents (mode "all")
-    const int kind = p.kind();
-    if (kind == MG_KIND_REDBLUEDOORS) {  // redbluedoors.py:176-185
-        const uint32_t cb = (blue_xy & 0xFF) * H + (blue_xy >> 8), cr = (red_xy & 0xFF) * H + (red_xy >> 8);
-        const uint32_t wb = cell_as_of_now(cb, fc[AC + 1]), wr = cell_as_of_now(cr, fc[AC]);
-#pragma unroll
-        for (int i = 0; i < AC; ++i) {
-            if (byte32(actw, i) != ACT_TOGGLE || front_xy(rx[i]) != blue_xy || (wb & 15) != T_DOOR) continue;
-            const int so = (flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
-            if (so != S_OPEN) continue;
-            if (((wr >> 4) & 15) == S_OPEN) {  // on_success, base.py:535-562
-                if (p.succ_any()) term_all = true; else term_some |= 1u << (8 * i);
-                rewmw = p.joint() ? ones : ((rewmw & ~(0xFFu << (8 * i))) | (1u << (8 * i)));
-            } else {  // on_failure, base.py:564-585
-                if (p.fail_any()) term_all = true; else term_some |= 1u << (8 * i);
-                flags |= FLAG_STALE;
-            }
-        }
-    } else if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {  // blockedunlockpickup.py:165-167
-        uint32_t boxw = 0;  // byte k: agent k carries the box
-#pragma unroll
-        for (int i = 0; i < AC; ++i)
-            if ((ry[i] & 0xFF) == T_BOX) boxw |= 1u << (8 * i);
-        if (boxw) {
-            // this environment always terminates "any" (blockedunlockpickup.py:128); the other branch is not
-            // reachable through the registry and keeps base.py:553-556 exact
-            if (p.succ_any()) term_all = true; else term_some |= boxw;
-            rewmw = p.joint() ? ones : ((rewmw & ~(boxw * 0xFFu)) | boxw);
-        }
-    } else if (kind == MG_KIND_LOCKEDHALLWAY) {  // locked_hallway.py:200-215
-#pragma unroll
-        for (int i = 0; i < AC; ++i) {
-            if (byte32(actw, i) != ACT_TOGGLE) continue;
-            const uint32_t ci = front_index(p, rx[i]);
-            if (ci == FC_NONE) continue;
-            const uint32_t w = cell_as_of_now(ci, fc[i]);
-            if ((w & 15) != T_DOOR || ((w >> 4) & 15) == S_LOCKED) continue;
-            const uint32_t bit = 1u << ((w >> 8) & 7);
-            if (flags & bit & FLAG_LH_MASK) continue;
-            flags |= bit & FLAG_LH_MASK;
-            rewmw += p.joint() ? ones : (1u << (8 * i));
-        }
-    }
-    if (term_all) term_some = ones;
-    toutw |= term_some;  // hooks set both the agents' own flags and the returned dict
-    if (kind == MG_KIND_LOCKEDHALLWAY && __popc(flags & FLAG_LH_MASK) == p.num_rooms())
-        toutw = ones;  // locked_hallway.py:213-215: only the returned dict
-
-    const bool all_term = toutw == ones;
-    const int paid = static_cast<int>(__builtin_amdgcn_sad_u8(rewmw, 0u, 0u));  // sum of the bytes
-    const bool over = trunc || all_term;
-    if (over) flags |= FLAG_OVER;
-    const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
-    // _reward() is only worked out (a double division) where somebody is paid: everybody else's reward is 0 * R
-    const double R = rewmw ? step_reward(p, step) : 0.0;
-
-    // ---- everything the step leaves ------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < AC; k += 2) {
-        const uint32_t t0 = byte32(term_some, k) ? 1u << 24 : 0u, t1 = byte32(term_some, k + 1) ? 1u << 24 : 0u;
-        *reinterpret_cast<uint4 *>(h + H_ROWS + 8 * k) =
-            make_uint4(t0 ? ((rx[k] & 0xFFFFFFu) | t0) : rx[k], ry[k], t1 ? ((rx[k + 1] & 0xFFFFFFu) | t1) : rx[k + 1], ry[k + 1]);
-    }
-    *reinterpret_cast<uint4 *>(h) = make_uint4(static_cast<uint32_t>(step), h0.y, (h0.z & ~0xFFu) | flags, h0.w);
-    if (AC == 4) *reinterpret_cast<uint4 *>(lds + p.o.log + 16 * slot) = make_uint4(logv[0], logv[1], logv[AC - 2], logv[AC - 1]);
-    else *reinterpret_cast<uint2 *>(lds + p.o.log + 8 * slot) = make_uint2(logv[0], logv[1]);
-    bytes_to(p.o.oterm, termw);
-    bytes_to(p.o.tout, toutw);
-    bytes_to(p.o.rewm, rewmw);
-    reinterpret_cast<double *>(lds + p.o.R)[slot] = R;
-    *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * slot) =
-        (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
-
-    // episode statistics: touched only when something happened (rare)
-    if (over && !was_over) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
-    }
-    if (paid != 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
-                  static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
-
-    // cells changed by this step go back to HBM unless the whole grid is about to be replaced
-    if (!will_reset && nlog > 0) {
-        uint16_t *gg = reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env) * p.GS);
-#pragma unroll
-        for (int j = 0; j < AC; ++j)
-            if (j < nlog) gg[logv[j] & 0xFFFF] = static_cast<uint16_t>(logv[j] >> 16);
-    }
-}
-
 // ---- act, one lane per agent -----------------------------------------------------------------------
 //
-// Agents of one environment rarely get in each other's way within a single step.  Every lane works
-// out its agent's action against the state at the start of the step and publishes what the others
-// need to know; a second look finds the pairs of agents for which the order of acting could matter:
-// a cell in front of one that the other may write, or - where it matters whether the cell in front is
-// occupied - an agent about to walk into or out of that cell.  Both agents of such a pair are left
-// untouched for the in-order replay in act_env*() (`tout` marks them); for all others the result is
-// final here, whatever the order, and neither depends on nor affects what the marked agents do.
-// Runs on the NE environments from `s0`; the scratch array lives in the image staging area, which is
-// idle during the act phase.
+// MultiGridEnv.step up to (not including) gen_obs, then the subclass hook: multigrid/base.py:395-396,440-533 and
+// redbluedoors.py:176-185, blockedunlockpickup.py:165-167, locked_hallway.py:200-215 - for the NE environments
+// of one sub-tile, every lane holding one agent.
+//
+// The grid itself is not needed.  Each agent acts once per step and only its own action moves or turns it, so the
+// cell in front of every agent is known before the first action: those A cells (plus the two RedBlueDoors doors)
+// travel with the header block - the observation pass of the previous launch left them there.  Cells written
+// during the step go to a short per-environment log that later readers of the same cell consult.
+//
+// Agents of one environment rarely get in each other's way within a single step.  Every lane works out its
+// agent's action against the state at the start of the step and publishes what the others need to know; a second
+// look finds the pairs of agents for which the order of acting could matter: a cell in front of one that the
+// other may write, or - where it matters whether the cell in front is occupied - an agent about to walk into or
+// out of that cell.  Both agents of such a pair are marked.  For all others the result is final at once, whatever
+// the order, and neither depends on nor affects what the marked agents do.  The marked agents then take their
+// turns in the lanes, in the environment's order (multigrid/base.py:457-464): round n belongs to the agent at
+// position n of its environment's order, rounds in which no marked agent of the wavefront acts are skipped, and an
+// agent at its turn sees the rows and the cell log as the earlier rounds left them - the reference's sequential
+// loop, run for the few agents it matters for.  Finally the environment's lanes settle the rest of the step
+// through ballots: terminations, truncation, the hook, rewards, episode statistics, changed cells to HBM.
+// The scratch array of the pair comparison lives in the image staging area, which is idle during the act phase.
 // CROWD: the kernel variant for 6 to 8 agents that may not overlap, where most steps have agents to compare: the
 // comparison goes through a cell-keyed table instead of over all pairs (kept out of the other variant, whose
 // code it would only lengthen).
@@ -1349,14 +813,16 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     ev.r = r0;
     ev.fxy = ev.ci = ev.w = ev.nv = ev.bits = 0u;
     int my_act = ACT_DONE;
-    uint32_t blue_xy = 0;
+    uint32_t blue_xy = 0, red_xy = 0, w0 = 0, flags = 0;
     if (mine) {
         r0 = *reinterpret_cast<const uint2 *>(a);  // x y dir term | ct cc cs color
-        const uint32_t w0 = reinterpret_cast<const uint16_t *>(h + p.HFC)[my_agent];
+        w0 = reinterpret_cast<const uint16_t *>(h + p.HFC)[my_agent];
         const uint2 hm = *reinterpret_cast<const uint2 *>(h + H_FLAGS);  // flags, door positions
         my_act = lds[p.o.act + s0 * A + lane];
+        flags = hm.x & 0xFF;
+        red_xy = hm.y & 0xFFFF;
         blue_xy = hm.y >> 16;
-        ev = eval_action(p, r0, w0, my_act, hm.x & 0xFF, blue_xy);
+        ev = eval_action(p, r0, w0, my_act, flags, blue_xy);
     }
     const bool need_occ = mine && needs_occupancy(p, ev);
     bool occupied = false, clash = false, unstable = false;
@@ -1492,106 +958,205 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         }
     }
     const uint64_t group = (A == 64 ? ~0ull : ((1ull << A) - 1ull)) << (my_slot * A);
-    const bool replay = (__ballot(clash) & group) != 0;  // some agents of my environment act later, in order
     finish_action(p, ev, r0, occupied);
     const bool final_here = mine && !clash;
-    const bool wr = final_here && (ev.bits & EV_WRITE);
-    const uint64_t writers = __ballot(wr) & group;
-    const uint64_t resync = __ballot(final_here && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE)) & group;
+    const uint64_t writers = __ballot(final_here && (ev.bits & EV_WRITE)) & group;
+    uint64_t resync = __ballot(final_here && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE));  // blue-door toggles re-sync cell and object
+    uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + (s0 + my_slot) * A;
+    int nlog = __popcll(writers);  // cells my environment has written so far
+    // my agent after its action (marked agents: not yet)
+    uint2 row = final_here ? ev.r : r0;
+    uint32_t my_term = (r0.x >> 24) | ((final_here && (ev.bits & EV_TERM)) ? 1u : 0u);
+    bool my_goal = final_here && (ev.bits & EV_GOAL);
     if (final_here) {
         if ((ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
-        if (wr)
-            reinterpret_cast<uint32_t *>(lds + p.o.log)[(s0 + my_slot) * A + __popcll(writers & ((1ull << lane) - 1ull))] =
-                ev.ci | (ev.nv << 16);
-        lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>((r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u));
-        lds[p.o.rewm + s0 * A + lane] = (ev.bits & EV_GOAL) ? 1 : 0;  // base.py:558-562
-    } else if (mine) {
-        lds[p.o.rewm + s0 * A + lane] = 0;  // base.py:454
+        if (ev.bits & EV_WRITE) log[__popcll(writers & ((1ull << lane) - 1ull))] = ev.ci | (ev.nv << 16);
     }
-    if (mine && replay) lds[p.o.tout + s0 * A + lane] = clash ? 1 : 0;  // who is left to act
-    const uint32_t word = (replay ? ACT_REPLAY : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) |
-                          (resync ? ACT_RESYNC : 0u);
-    // Where no agent of an environment is left to act, the rest of the step (multigrid/base.py:395-402, the
-    // environment's hook and the bookkeeping of act_env*()) is done here, the environment's lanes agreeing through
-    // ballots.  The hooks look at the state the actions left (they run after gen_obs in the reference, on the
-    // returned dicts), agents in index order and - a quirk kept - terminated agents included:
-    //   Empty                no hook;
-    //   BlockedUnlockPickup  anybody carrying the box: success for all (blockedunlockpickup.py:165-167);
-    //   LockedHallway        every door that is not locked, faces a toggling agent and has not paid yet pays once
-    //                        (locked_hallway.py:200-215); left to act_env*() when a terminated agent toggles, whose
-    //                        front cell is not tracked here;
-    //   RedBlueDoors         nothing unless somebody toggles towards the blue door (redbluedoors.py:176-185): those
-    //                        environments are left to act_env*().
-    const int kind = p.kind();
-    bool hook_here = kind == MG_KIND_EMPTY;
-    bool carrier = false;   // BlockedUnlockPickup: carries the box after the actions
-    uint32_t lh_bit = 0;    // LockedHallway: colour bit of the unlocked door I toggle towards
-    if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
-        hook_here = p.succ_any();  // the class always terminates "any" (blockedunlockpickup.py:128)
-        carrier = mine && ((clash ? r0.y : ev.r.y) & 0xFF) == T_BOX;
-    } else if (kind == MG_KIND_LOCKEDHALLWAY) {
-        const bool toggles = mine && my_act == ACT_TOGGLE;
-        hook_here = (__ballot(toggles && !(ev.bits & EV_ALIVE)) & group) == 0;
-        const uint32_t wa = (ev.bits & EV_WRITE) ? ev.nv : ev.w;  // the cell in front as the step leaves it
-        if (toggles && (ev.bits & EV_ONCELL) && (wa & 15) == T_DOOR && ((wa >> 4) & 15) != S_LOCKED)
-            lh_bit = (1u << ((wa >> 8) & 7)) & FLAG_LH_MASK;
-    } else if (kind == MG_KIND_REDBLUEDOORS) {
-        hook_here = (__ballot(mine && my_act == ACT_TOGGLE && ev.fxy == blue_xy) & group) == 0;
-    }
-    {
-        const bool done = mine && !replay && hook_here;
-        const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | meta
-        const int step = static_cast<int>(h0.x) + 1;           // base.py:395
-        uint32_t flags = h0.z & 0xFF;
-        const uint32_t my_term = (r0.x >> 24) | ((ev.bits & EV_TERM) ? 1u : 0u);
-        const uint64_t goals = __ballot(done && (ev.bits & EV_GOAL)) & group;
-        uint32_t my_tout = my_term;                                                                // base.py:400
-        uint32_t my_rewm = p.joint() ? (goals ? 1u : 0u) : ((ev.bits & EV_GOAL) ? 1u : 0u);         // base.py:558-562
-        bool hook_term = false;  // the hook terminated my agent (its own flag too, not only the returned one)
-        if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
-            if (__ballot(done && carrier) & group) {  // on_success with mode "any": everybody, base.py:547-552
-                hook_term = true;
-                my_tout = 1;
-                if (p.joint() || carrier) my_rewm = 1;
-            }
-        } else if (kind == MG_KIND_LOCKEDHALLWAY) {
-            uint32_t newbits = 0, first = 0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const uint64_t m = __ballot(done && lh_bit == (1u << c)) & group;
-                if (m != 0 && !(flags & (1u << c))) {
-                    newbits |= 1u << c;
-                    if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+    const uint64_t left = __ballot(clash);  // marked agents: they act one by one, in the order of base.py:457-464
+    const bool replayed = (left & group) != 0;
+    if (left != 0) {
+        uint8_t *ordb = lds + p.o.ord + (s0 + my_slot) * A;
+        if (p.order == nullptr) {  // the environment's order of this step, drawn once per environment: see order_key()
+            if (replayed && my_agent == 0) {
+                const uint2 hs = *reinterpret_cast<const uint2 *>(h);  // step_count, episode
+                const uint32_t key = order_key(p, env0 + s0 + my_slot, hs.y, static_cast<int>(hs.x) + 1);
+                uint32_t word = 0;
+                if (A <= 8) {
+                    uint64_t ordw = 0x0706050403020100ull;
+#pragma unroll 1
+                    for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                        const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                        const uint64_t d = ((ordw >> (8 * k)) ^ (ordw >> (8 * j))) & 0xFF;
+                        ordw ^= (d << (8 * k)) ^ (d << (8 * j));
+                    }
+#pragma unroll 1
+                    for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(ordw >> (8 * k));
+                } else {
+#pragma unroll 1
+                    for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
+#pragma unroll 1
+                    for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                        const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                        const uint8_t t = ordb[k];
+                        ordb[k] = ordb[j];
+                        ordb[j] = t;
+                    }
                 }
             }
-            my_rewm += p.joint() ? static_cast<uint32_t>(__popc(newbits)) : first;  // `+=`, locked_hallway.py:207-211
-            flags |= newbits;
-            if (__popc(flags & FLAG_LH_MASK) == p.num_rooms()) my_tout = 1;  // only the returned dict, :213-215
+            wave_sync();
         }
-        const bool all_term = (__ballot(done && my_tout != 0) & group) == group;
+        int pos = -1;  // my agent's place in the order
+        if (clash) {
+#pragma unroll 1
+            for (int n = A - 1; n >= 0; --n)
+                if (ordb[n] == my_agent) pos = n;
+        }
+        if (resync & group) flags &= ~FLAG_STALE;
+#pragma unroll 1
+        for (int n = 0; n < A; ++n) {  // base.py:464
+            const bool turn = clash && pos == n;
+            if (__ballot(turn) == 0) continue;
+            if (turn) {
+                uint32_t w = w0;  // the cell in front as the agents before me have left it
+#pragma unroll 1
+                for (int j = 0; j < nlog; ++j) {
+                    const uint32_t e = log[j];
+                    if ((e & 0xFFFF) == ev.ci) w = e >> 16;
+                }
+                ev = eval_action(p, r0, w, my_act, flags, blue_xy);
+                bool occ = false;  // base.py:485,512: every agent counts, terminated ones included
+                if (needs_occupancy(p, ev))
+#pragma unroll 1
+                    for (int k = 0; k < A; ++k) occ |= *reinterpret_cast<const uint16_t *>(h + H_ROWS + 8 * k) == ev.fxy;
+                finish_action(p, ev, r0, occ);
+                if (ev.bits & EV_ALIVE) {
+                    if (ev.r.x != r0.x || ev.r.y != r0.y) *reinterpret_cast<uint2 *>(a) = ev.r;
+                    row = ev.r;
+                }
+                if (ev.bits & EV_WRITE) log[nlog] = ev.ci | (ev.nv << 16);
+                if (ev.bits & EV_TERM) my_term = 1;
+                my_goal = (ev.bits & EV_GOAL) != 0;
+            }
+            if (__ballot(turn && (ev.bits & EV_WRITE)) & group) ++nlog;
+            const uint64_t rs = __ballot(turn && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE));
+            resync |= rs;
+            if (rs & group) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+            wave_sync();  // the next round sees this round's rows and cells
+        }
+    }
+    if (resync & group) flags &= ~FLAG_STALE;
+
+    // ---- the rest of the step, the environment's lanes agreeing through ballots ---------------------------
+    // The hooks look at the state the actions left (they run after gen_obs in the reference, on the returned
+    // dicts), agents in index order and - a quirk kept - terminated agents included:
+    //   Empty                no hook;
+    //   BlockedUnlockPickup  anybody carrying the box: success (blockedunlockpickup.py:165-167);
+    //   LockedHallway        every door that is not locked, faces a toggling agent and has not paid yet pays once,
+    //                        to the lowest-index such agent or to all (locked_hallway.py:200-215);
+    //   RedBlueDoors         agents toggling towards the open blue door: success for each of them while the red door
+    //                        is open, else failure for the first, which re-closes the door OBJECT and so ends the
+    //                        matter for the others (redbluedoors.py:176-185).
+    const int kind = p.kind();
+    // the cell a toggling agent faces as the step leaves it (a toggle neither moves nor turns the agent)
+    auto cell_at_end = [&](uint32_t ci, uint32_t at_start) {
+        uint32_t w = at_start;
+#pragma unroll 1
+        for (int j = 0; j < nlog; ++j) {
+            const uint32_t e = log[j];
+            if ((e & 0xFFFF) == ci) w = e >> 16;
+        }
+        return w;
+    };
+    const bool toggles = mine && my_act == ACT_TOGGLE;
+    const bool faces_cell = (ev.fxy & 0xFF) < static_cast<uint32_t>(p.W()) && (ev.fxy >> 8) < static_cast<uint32_t>(p.H());
+    const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | meta
+    const int step = static_cast<int>(h0.x) + 1;           // base.py:395
+    const uint32_t was_over = h0.z & FLAG_OVER;
+    const uint64_t goals = __ballot(mine && my_goal) & group;
+    uint32_t my_tout = my_term;                                                     // base.py:400
+    uint32_t my_rewm = p.joint() ? (goals ? 1u : 0u) : (my_goal ? 1u : 0u);         // base.py:558-562
+    bool hook_term = false;  // the hook terminated my agent (its own flag too, not only the returned one)
+    if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
+        const bool carrier = mine && (row.y & 0xFF) == T_BOX;
+        if (__ballot(carrier) & group) {  // on_success, base.py:535-562
+            hook_term = p.succ_any() || carrier;
+            if (hook_term) my_tout = 1;
+            if (p.joint() || carrier) my_rewm = 1;
+        }
+    } else if (kind == MG_KIND_LOCKEDHALLWAY) {
+        uint32_t lh_bit = 0;  // colour bit of the unlocked door I toggle towards
+        if (toggles && faces_cell) {
+            const uint32_t wa = cell_at_end(ev.ci, w0);
+            if ((wa & 15) == T_DOOR && ((wa >> 4) & 15) != S_LOCKED) lh_bit = (1u << ((wa >> 8) & 7)) & FLAG_LH_MASK;
+        }
+        uint32_t newbits = 0, first = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const uint64_t m = __ballot(lh_bit == (1u << c)) & group;
+            if (m != 0 && !(flags & (1u << c))) {
+                newbits |= 1u << c;
+                if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+            }
+        }
+        my_rewm += p.joint() ? static_cast<uint32_t>(__popc(newbits)) : first;  // `+=`, locked_hallway.py:207-211
+        flags |= newbits;
+        if (__popc(flags & FLAG_LH_MASK) == p.num_rooms()) my_tout = 1;  // only the returned dict, :213-215
+    } else if (kind == MG_KIND_REDBLUEDOORS) {
+        const bool cand = toggles && ev.fxy == blue_xy;
+        const uint64_t cands = __ballot(cand) & group;
+        if (cands) {
+            const uint16_t *fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
+            const uint32_t wb = cell_at_end((blue_xy & 0xFF) * p.H() + (blue_xy >> 8), fcv[A + 1]);
+            const uint32_t wr = cell_at_end((red_xy & 0xFF) * p.H() + (red_xy >> 8), fcv[A]);
+            const int so = (flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
+            if ((wb & 15) == T_DOOR && so == S_OPEN) {
+                if (((wr >> 4) & 15) == S_OPEN) {  // on_success for every one of them, base.py:535-562
+                    hook_term = p.succ_any() || cand;
+                    if (p.joint() || cand) my_rewm = 1;
+                } else {  // on_failure for the first, base.py:564-585
+                    hook_term = p.fail_any() || (cand && __builtin_ctzll(cands) == lane);
+                    flags |= FLAG_STALE;
+                }
+                if (hook_term) my_tout = 1;
+            }
+        }
+    }
+    {
+        const bool all_term = (__ballot(mine && my_tout != 0) & group) == group;
         const bool trunc = step >= p.max_steps;  // base.py:401-402
         const bool over = trunc || all_term;
         const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
-        const int paid = __popcll(__ballot(done && (my_rewm & 1)) & group) + 2 * __popcll(__ballot(done && (my_rewm & 2)) & group) +
-                         4 * __popcll(__ballot(done && (my_rewm & 4)) & group);
-        if (done) {
+        const int paid = __popcll(__ballot(mine && (my_rewm & 1)) & group) + 2 * __popcll(__ballot(mine && (my_rewm & 2)) & group) +
+                         4 * __popcll(__ballot(mine && (my_rewm & 4)) & group);
+        if (mine) {
+            lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>(my_term);  // what gen_obs sees (base.py:399)
             lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_tout);
             lds[p.o.rewm + s0 * A + lane] = static_cast<uint8_t>(my_rewm);
             if (hook_term) a[R_TERM] = 1;
-            // a cell changed by this step goes back to HBM unless the whole grid is about to be replaced
-            if (wr && !will_reset)
-                reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env0 + s0 + my_slot) * p.GS)[ev.ci] =
-                    static_cast<uint16_t>(ev.nv);
+            // cells changed by this step go back to HBM unless the whole grid is about to be replaced: every agent
+            // its own where all were independent (no two of them wrote one cell), else the log in its order
+            if (!will_reset && nlog > 0) {
+                uint16_t *gg = reinterpret_cast<uint16_t *>(late_arg<uint8_t *>(offsetof(KParams, grid)) +
+                                                            static_cast<size_t>(env0 + s0 + my_slot) * p.GS);
+                if (!replayed) {
+                    if (ev.bits & EV_WRITE) gg[ev.ci] = static_cast<uint16_t>(ev.nv);
+                } else if (my_agent == 0) {
+#pragma unroll 1
+                    for (int j = 0; j < nlog; ++j) {
+                        const uint32_t e = log[j];
+                        gg[e & 0xFFFF] = static_cast<uint16_t>(e >> 16);
+                    }
+                }
+            }
             if (my_agent == 0) {
                 const double R = paid != 0 ? step_reward(p, step) : 0.0;  // nobody paid: every reward is 0 * R
                 *reinterpret_cast<int *>(h + H_STEP) = step;
                 h[H_FLAGS] = static_cast<uint8_t>(flags | (over ? FLAG_OVER : 0u));
                 reinterpret_cast<double *>(lds + p.o.R)[s0 + my_slot] = R;
                 *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) =
-                    (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(__popcll(writers)) << 16) |
-                    ACT_FINISHED;
+                    (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
                 // episode statistics: touched only when something happened (rare)
-                if (over && !(flags & FLAG_OVER)) {
+                if (over && !was_over) {
                     atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 0), 1ull);
                     atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 1), static_cast<unsigned long long>(step));
                     atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + (all_term ? 2 : 3)), 1ull);
@@ -1600,8 +1165,6 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                     atomicAdd(reinterpret_cast<unsigned long long *>(stats_shard() + 4),
                               static_cast<unsigned long long>(static_cast<long long>(paid * R * 16777216.0)));
             }
-        } else if (mine && my_agent == 0) {  // picked up by act_env*()
-            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) = word;
         }
     }
     wave_sync();
@@ -1833,7 +1396,7 @@ __device__ __forceinline__ void emit_one_hot(const KParams &p, uint8_t *lds, con
 // flags go out (plus the few grid cells a step changes, which still go to HBM at once, and restarts from the pool).
 // COMP: a step of CompetativeRedBlueDoor environments (their hook runs after gen_obs and moves agents).
 // STG: agents whose images share the LDS staging buffer on their way out (16, 32 or 64; the host picks per batch).
-template <int V, bool SEE, int MODE, bool SMALLA, bool WALLED, bool OH, bool MULTI = false, bool COMP = false,
+template <int V, bool SEE, int MODE, bool WALLED, bool OH, bool MULTI = false, bool COMP = false,
           bool CROWD = false, int STG = MG_STAGE_LANES>
 #ifndef MG_KERNEL_ATTR
 #define MG_KERNEL_ATTR
@@ -1852,8 +1415,8 @@ __global__ __launch_bounds__(64) MG_KERNEL_ATTR
 __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))) void mg_tile_kernel(const KParams p0) {
     extern __shared__ __align__(16) uint8_t lds[];
     static_assert(!MULTI || (MODE == MODE_STEP && !OH), "the multi-step kernel steps and writes compact images");
-    static_assert(!COMP || (MODE == MODE_STEP && SMALLA && !OH && !WALLED), "CompetativeRedBlueDoor steps: one variant");
-    static_assert(!CROWD || (MODE == MODE_STEP && SMALLA && !OH && !COMP), "the cell table serves steps of up to 8 agents");
+    static_assert(!COMP || (MODE == MODE_STEP && !OH && !WALLED), "CompetativeRedBlueDoor steps: one variant");
+    static_assert(!CROWD || (MODE == MODE_STEP && !OH && !COMP), "the cell table serves steps of up to 8 agents");
     static_assert(STG == 16 || STG == 32 || STG == 64, "staging width: whole 16-agent blocks of a wavefront");
     // the multi-step kernel advances its input / output pointers from step to step; otherwise p is never written
     typename std::conditional<MULTI, KParams, const KParams &>::type p = p0;
@@ -1875,7 +1438,6 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     if ((p.dbg & 64) && ((blockIdx.x >> ((p.dbg >> 16) & 31)) & 1))
         for (int i = 0, n = (p.dbg >> 8) & 255; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     )
-    constexpr bool small = SMALLA;  // A <= 8, chosen by the host
     // which environments take part (a masked reset skips some)
     bool active = lane < net;
     if (MODE == MODE_RESET && active && p.mask) active = p.mask[e0 + lane] != 0;
@@ -1926,9 +1488,15 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
 #pragma unroll 1
             for (int i = 64 * MG_PREFETCH_REGS + lane; i < n16_; i += 64) dg_[i + gpq * udiv(i, p.magic_per)] = src_[i];
         }
+    };
+    // environments of a sub-tile that were restarted in this launch: their grid in LDS comes from the layout pool
+    // (`gslot_`: where the sub-tile's grids start in LDS)
+    auto patch = [&](int s0_, int gslot_) {
+        const int ns_ = min(NE, net - s0_);
         if (MODE != MODE_OBS && __ballot(lane < ns_ && lsrc[s0_ + lane] >= 0)) {
-            // environments restarted in this launch: their grid comes from the layout pool
             const uint8_t *pool_grid_ = late_arg<const uint8_t *>(offsetof(KParams, pool_grid));
+            const int n16_ = ns_ * per;
+            uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid + gslot_ * p.GP);
 #pragma unroll 1
             for (int i = lane; i < n16_; i += 64) {
                 const int sub = udiv(i, p.magic_per);
@@ -2085,48 +1653,17 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         }
         wave_sync();
     }
-    if (MODE == MODE_STEP) {
-        if (p.lanes_act() && !COMP) {
-#pragma unroll 1
-            for (int s0 = 0; s0 < net; s0 += NE) act_lanes<CROWD>(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
-        } else if (lane < net) {
-            *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * lane) = ACT_REPLAY_ALL;  // every agent acts in order
-        }
-        wave_sync();
-        MG_EXP(
-        MG_TICK(ta1);
-        const int n_replay = __popcll(__ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0));
-        )
-        // environments that act_lanes() could not finish: hooks, or agents whose actions interact
-        if (__ballot(lane < net && !(*reinterpret_cast<const uint32_t *>(lds + p.o.flag + 4 * lane) & ACT_FINISHED)) != 0 &&
-            lane < net) {
-            if constexpr (small) {
-                if (!COMP && A == 2)
-                    act_env_fixed<2>(p, lds, lane, e0 + lane);
-                else if (!COMP && A == 4)
-                    act_env_fixed<4>(p, lds, lane, e0 + lane);
-                else
-                    act_env_small<COMP>(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
-                                        p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
-            } else {
-                act_env(p, lds, lane, e0 + lane);
-            }
-        }
-        wave_sync();
-        // (diagnostic builds: staging, act with a lane per agent, act with a lane per environment, replayed environments)
-        MG_EXP(
-        MG_TICK(ta2);
-        if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
-            unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 20;
-            d[0] = ta0 - tstart;
-            d[1] = ta1 - ta0;
-            d[2] = ta2 - ta1;
-            d[4] = n_replay;
-        }
-        )
-        MG_STAMP(2);
+    // CompetativeRedBlueDoor steps (in-order act phase, one lane per environment) and the cell-table variant (its
+    // table lies where the grids go) act on the whole tile before the first view is taken; all others take the
+    // tile one sub-tile at a time - act, view, images out - so that the image stores of one sub-tile drain while the
+    // next one acts.
+#ifndef MG_INTERLEAVE_ACT
+#define MG_INTERLEAVE_ACT 0
+#endif
+    constexpr bool ACT_FIRST = COMP || CROWD || !MG_INTERLEAVE_ACT;
+    // the multi-step kernel's next actions set out once this step's are no longer needed in registers
+    auto prefetch_actions = [&]() {
         if (MULTI && t + 1 < p.T) {
-            // the act phase has consumed this step's actions: the next step's set out now and arrive during the views
             const size_t ea = static_cast<size_t>(p.E) * A;
             const uint8_t *ga = p.actions + ea + static_cast<size_t>(e0) * A;
             const uint8_t *go = p.order ? p.order + ea + static_cast<size_t>(e0) * A : nullptr;
@@ -2136,50 +1673,54 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 if (go) ow_next = *reinterpret_cast<const uint32_t *>(go + 4 * lane);
             }
         }
-        if (p.autoreset() == MG_AUTORESET_SAME_STEP) {
-            uint64_t m = __ballot(lane < net && lds[p.o.flag + 4 * lane + 1] != 0);
-            if (m) {
-                while (m) {
-                    const int s = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int env = e0 + s;
-                    const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HP + H_EPISODE) + 1u;
-                    const int layout = pick_layout(p, env, episode);
-                    wave_sync();
-                    reload_env(p, lds, s, env, layout, episode, lane);
-                    if (lane == 0) lsrc[s] = layout;
-                    if (lane == 0) lds[p.o.flag + 4 * s + 2] = 0;  // the fresh grid takes no patches
-                    if (lane == 0) lds[p.o.flag + 4 * s + 3] = 0;
-                    wave_sync();
-                    if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HP + H_ROWS + 8 * lane + R_TERM];
-                    if (COMP && lane < A)  // nothing of the hook is left to apply: the agents stand where the layout puts them
-                        reinterpret_cast<uint16_t *>(lds + p.o.pxy)[s * A + lane] =
-                            *reinterpret_cast<const uint16_t *>(lds + p.o.hdr + s * p.HP + H_ROWS + 8 * lane);
-                }
+    };
+    // MG_AUTORESET_SAME_STEP: environments [first, first + count) of the tile whose episode ended in this step take
+    // their next start state now, before the views are made
+    auto restart_now = [&](int first, int count) {
+        if (p.autoreset() != MG_AUTORESET_SAME_STEP) return;
+        uint64_t m = __ballot(lane >= first && lane < first + count && lds[p.o.flag + 4 * lane + 1] != 0);
+        if (m) {
+            while (m) {
+                const int s = __builtin_ctzll(m);
+                m &= m - 1;
+                const int env = e0 + s;
+                const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HP + H_EPISODE) + 1u;
+                const int layout = pick_layout(p, env, episode);
                 wave_sync();
+                reload_env(p, lds, s, env, layout, episode, lane);
+                if (lane == 0) lsrc[s] = layout;
+                if (lane == 0) lds[p.o.flag + 4 * s + 2] = 0;  // the fresh grid takes no patches
+                if (lane == 0) lds[p.o.flag + 4 * s + 3] = 0;
+                wave_sync();
+                if (lane < A) lds[p.o.oterm + s * A + lane] = lds[p.o.hdr + s * p.HP + H_ROWS + 8 * lane + R_TERM];
+                if (COMP && lane < A)  // nothing of the hook is left to apply: the agents stand where the layout puts them
+                    reinterpret_cast<uint16_t *>(lds + p.o.pxy)[s * A + lane] =
+                        *reinterpret_cast<const uint16_t *>(lds + p.o.hdr + s * p.HP + H_ROWS + 8 * lane);
             }
+            wave_sync();
         }
+    };
+    if (MODE == MODE_STEP && ACT_FIRST) {
+        if constexpr (COMP) {
+            if (lane < net) {
+                act_env_small<true>(p, lds, lane, e0 + lane, load_bytes(lds + p.o.act + lane * A, A),
+                                    p.order ? load_bytes(lds + p.o.ord + lane * A, A) : 0ull);
+            }
+        } else {
+#pragma unroll 1
+            for (int s0 = 0; s0 < net; s0 += NE) act_lanes<CROWD>(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
+        }
+        wave_sync();
+        MG_STAMP(2);
+        prefetch_actions();
+        restart_now(0, net);
     }
 
     MG_STAMP(3);
-    // ---- observe: NE environments at a time -------------------------------------------------------------
+    // ---- act (unless done above) and observe: NE environments at a time ---------------------------------------
     if (passes) {
         uint8_t *out_image = p.image;
         if constexpr (!MULTI) out_image = late_arg<uint8_t *>(offsetof(KParams, image));  // (see the per-agent scalars)
-        if (MULTI) {
-            patch_all_grids();
-        } else {
-            if (MODE == MODE_RESET) issue(0);
-            commit(0);
-        }
-        wave_sync();
-        MG_EXP(
-        {
-            unsigned long long tb = 0;
-            MG_TICK(tb);
-            if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 29] = tb - ta2;
-        }
-        )
         for (int s0 = 0; s0 < net; s0 += NE) {
             const int ns = min(NE, net - s0);
             const int np = ns * A;
@@ -2188,9 +1729,23 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             const bool has_next = !MULTI && s0 + NE < net;
             const int gslot0 = MULTI ? s0 : 0;  // where the sub-tile's grids start in LDS
             MG_EXP(
-            unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+            unsigned long long tk0 = 0, tka = 0, tk1 = 0, tk2 = 0, tk3 = 0;
             MG_TICK(tk0);
             )
+            if (MODE == MODE_STEP && !ACT_FIRST) {
+                act_lanes<false>(p, lds, e0, s0, ns, lane, my_slot, my_agent);
+                if (s0 == 0) prefetch_actions();
+                restart_now(s0, ns);
+            }
+            MG_EXP(MG_TICK(tka);)
+            // the sub-tile's grids: the first ones were set out when the launch began, the others came in at the
+            // end of the pass before; what was restarted in this launch is taken from the pool
+            if (!MULTI && s0 == 0) {
+                if (MODE == MODE_RESET) issue(0);
+                commit(0);
+            }
+            patch(s0, gslot0);
+            wave_sync();
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
             const uint8_t *my_hdr = lds + p.o.hdr + (s0 + my_slot) * p.HP;
@@ -2412,15 +1967,16 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 wave_sync();
             }
             if (s0 == 0) MG_STAMP(8);
-            // (diagnostic builds: compute, commit of the prefetched grids, copy-out, per pass)
+            // (diagnostic builds: compute, commit of the prefetched grids, copy-out, passes, act of the sub-tile)
             MG_EXP(
             MG_TICK(tk3);
             if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
                 unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 16;
-                d[0] += tk1 - tk0;
+                d[0] += tk1 - tka;
                 d[1] += tk2 - tk1;
                 d[2] += tk3 - tk2;
                 d[3] += 1;
+                d[4] += tka - tk0;
             }
             )
         }
@@ -2971,96 +2527,79 @@ int fail(MgEnv *h, int code, const char *fmt, ...) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int V, int MODE, bool WALLED, bool OH, bool MULTI = false>
-void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s);
+// One instantiation of the tile kernel per combination the dispatch below can reach:
+//   view size x see-through x mode, then
+//   steps of CompetativeRedBlueDoor environments (general border code, compact images), one or many per launch;
+//   steps of the other kinds: many per launch (mg_step_n), or one per launch with the cell-table act phase, or one per
+//     launch with the staging width picked for the batch (16 / 32 / 64) - each for walled and for general grids;
+//   launches of any mode that also write one-hot images (bound by those stores: general border code);
+//   reset and gen_obs launches, walled or general.
+template <int V, bool SEE, int MODE, bool WALLED, bool OH, bool MULTI, bool COMP, bool CROWD, int STG>
+void launch_k(const MgEnv *h, const KParams &kp, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((mg_tile_kernel<V, SEE, MODE, WALLED, OH, MULTI, COMP, CROWD, STG>), dim3(h->num_tiles), dim3(64), lds, s, kp);
+}
 
-// steps of CompetativeRedBlueDoor environments (at most 8 agents, compact images, general border code)
-template <int V, bool MULTI>
-void launch_comp(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
-    const dim3 grid(h->num_tiles), block(64);
+template <int V, bool SEE, int MODE>
+void launch_vs(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
     KParams kp = kp_in;
+    constexpr int STG0 = MG_STAGE_LANES;
     size_t lds = h->lds_bytes;
-    if (MULTI) {
-        kp.o = h->o_multi;
-        lds = h->lds_multi;
-    }
-    if (h->cfg.see_through_walls)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE_STEP, true, false, false, MULTI, true>), grid, block, lds, s, kp);
-    else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE_STEP, true, false, false, MULTI, true>), grid, block, lds, s, kp);
-}
-
-template <int V, int MODE, bool WALLED, bool OH, bool MULTI>
-void launch_vmw(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
-    const dim3 grid(h->num_tiles), block(64);
-    KParams kp = kp_in;
-    size_t lds = h->lds_bytes + (OH ? OH_XCHG_BYTES : 0);
-    if (MULTI) {
-        kp.o = h->o_multi;
-        lds = h->lds_multi;
-    } else {
-        kp.o.oh = static_cast<int>(h->lds_bytes);  // the exchange buffer follows everything else
-    }
-    const bool see = h->cfg.see_through_walls != 0, small = h->cfg.num_agents <= 8;
-    if constexpr (MODE == MODE_STEP && !OH && !MULTI) {
-        // plain steps of up to 8 agents: the staging width picked for this batch, with the LDS map that goes with it
-        if (small && !h->crowd && h->stg_step != MG_STAGE_LANES) {
-            const int oh = kp.o.oh;
-            kp.o = h->o_step;
-            kp.o.oh = oh;
-            lds = h->lds_step;
-#define MG_LAUNCH_STG(SEE_, STG_) \
-    hipLaunchKernelGGL((mg_tile_kernel<V, SEE_, MODE, true, WALLED, false, false, false, false, STG_>), grid, block, lds, s, kp)
-            if (h->stg_step == 16) {
-                if (see) MG_LAUNCH_STG(true, 16); else MG_LAUNCH_STG(false, 16);
-            } else {
-                if (see) MG_LAUNCH_STG(true, 64); else MG_LAUNCH_STG(false, 64);
-            }
-#undef MG_LAUNCH_STG
-            return;
-        }
-    }
-    if constexpr (MODE == MODE_STEP && !OH) {
-        if (h->crowd) {
-            if (see)
-                hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH, MULTI, false, true>), grid, block, lds, s, kp);
-            else
-                hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH, MULTI, false, true>), grid, block, lds, s, kp);
-            return;
-        }
-    }
-    if (see && small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, true, WALLED, OH, MULTI>), grid, block, lds, s, kp);
-    else if (see)
-        hipLaunchKernelGGL((mg_tile_kernel<V, true, MODE, false, WALLED, OH, MULTI>), grid, block, lds, s, kp);
-    else if (small)
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, true, WALLED, OH, MULTI>), grid, block, lds, s, kp);
-    else
-        hipLaunchKernelGGL((mg_tile_kernel<V, false, MODE, false, WALLED, OH, MULTI>), grid, block, lds, s, kp);
-}
-
-template <int V, int MODE>
-void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
+    kp.o.oh = static_cast<lds_off_t>(h->lds_bytes);  // the one-hot exchange buffer follows everything else
     if constexpr (MODE == MODE_STEP) {
+        const bool multi = kp.T > 1;
+        if (multi) {
+            kp.o = h->o_multi;
+            lds = h->lds_multi;
+        }
         if (kp.comp()) {
-            if (kp.T > 1) launch_comp<V, true>(h, kp, s); else launch_comp<V, false>(h, kp, s);
+            if (multi) launch_k<V, SEE, MODE, false, false, true, true, false, STG0>(h, kp, lds, s);
+            else launch_k<V, SEE, MODE, false, false, false, true, false, STG0>(h, kp, lds, s);
             return;
         }
-        if (kp.T > 1) {  // mg_step_n: one launch for T steps (never with one-hot images)
-            if (kp.walled())
-                launch_vmw<V, MODE, true, false, true>(h, kp, s);
-            else
-                launch_vmw<V, MODE, false, false, true>(h, kp, s);
+        if (multi) {  // mg_step_n: one launch for T steps (never with one-hot images)
+            if (h->crowd) {
+                if (kp.walled()) launch_k<V, SEE, MODE, true, false, true, false, true, STG0>(h, kp, lds, s);
+                else launch_k<V, SEE, MODE, false, false, true, false, true, STG0>(h, kp, lds, s);
+            } else {
+                if (kp.walled()) launch_k<V, SEE, MODE, true, false, true, false, false, STG0>(h, kp, lds, s);
+                else launch_k<V, SEE, MODE, false, false, true, false, false, STG0>(h, kp, lds, s);
+            }
             return;
+        }
+        if (!kp.onehot) {
+            if (h->crowd) {
+                if (kp.walled()) launch_k<V, SEE, MODE, true, false, false, false, true, STG0>(h, kp, lds, s);
+                else launch_k<V, SEE, MODE, false, false, false, false, true, STG0>(h, kp, lds, s);
+                return;
+            }
+            if (h->stg_step != STG0) {  // the staging width picked for this batch, with the LDS map that goes with it
+                const lds_off_t oh = kp.o.oh;
+                kp.o = h->o_step;
+                kp.o.oh = oh;
+                lds = h->lds_step;
+                if (h->stg_step == 16) {
+                    if (kp.walled()) launch_k<V, SEE, MODE, true, false, false, false, false, 16>(h, kp, lds, s);
+                    else launch_k<V, SEE, MODE, false, false, false, false, false, 16>(h, kp, lds, s);
+                } else {
+                    if (kp.walled()) launch_k<V, SEE, MODE, true, false, false, false, false, 64>(h, kp, lds, s);
+                    else launch_k<V, SEE, MODE, false, false, false, false, false, 64>(h, kp, lds, s);
+                }
+                return;
+            }
         }
     }
     // launches that also write one-hot images are bound by those stores; they share the general-border code
     if (kp.onehot)
-        launch_vmw<V, MODE, false, true>(h, kp, s);
+        launch_k<V, SEE, MODE, false, true, false, false, false, STG0>(h, kp, lds + OH_XCHG_BYTES, s);
     else if (kp.walled())
-        launch_vmw<V, MODE, true, false>(h, kp, s);
+        launch_k<V, SEE, MODE, true, false, false, false, false, STG0>(h, kp, lds, s);
     else
-        launch_vmw<V, MODE, false, false>(h, kp, s);
+        launch_k<V, SEE, MODE, false, false, false, false, false, STG0>(h, kp, lds, s);
+}
+
+template <int V, int MODE>
+void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
+    if (h->cfg.see_through_walls) launch_vs<V, true, MODE>(h, kp, s); else launch_vs<V, false, MODE>(h, kp, s);
 }
 
 template <int MODE>
@@ -3192,12 +2731,8 @@ int configure(MgEnv *h, const MgConfig &c) {
     // Small batches get small tiles: the launch then has enough wavefronts to cover the chip and
     // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
-    bool lanes_act = c.num_agents >= PARALLEL_ACT_MIN_AGENTS ||
-                     (c.num_agents >= 2 && (c.kind == MG_KIND_EMPTY || c.kind == MG_KIND_REDBLUEDOORS));
-    if (const char *ev = tuning_env("MGRID_LANES_ACT")) lanes_act = atoi(ev) != 0 && c.num_agents >= 2;  // tuning / test override
-    lanes_act = lanes_act && c.kind != MG_KIND_COMPETITIVE;
-    if (lanes_act) kp.bits |= 1u << 26;
-    h->crowd = lanes_act && !c.allow_agent_overlap && c.num_agents >= PARALLEL_ACT_MIN_AGENTS && c.num_agents <= 8;
+    // (CompetativeRedBlueDoor environments act in order, one lane per environment; all others one lane per agent)
+    h->crowd = c.kind != MG_KIND_COMPETITIVE && !c.allow_agent_overlap && c.num_agents >= CROWD_MIN_AGENTS && c.num_agents <= 8;
     if (const char *ev = tuning_env("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
     auto lds_for = [&](int ne, int g, bool multi = false, int stg = STAGE_LANES) {
         const int et = ne * g, np = ne * c.num_agents;
@@ -3273,10 +2808,10 @@ int configure(MgEnv *h, const MgConfig &c) {
         // 131072 x 8 agents than 32 and 5 % on 2^20 x 8, where 64 is 6 % slower).  The cell-table variant stays
         // at 32 (16 measured 2 % slower there).
         const int tiles = (c.num_envs + ne * g - 1) / (ne * g);
-        h->stg_step = h->crowd ? 32 : tiles <= 2048 ? 64 : (lanes_act && c.num_agents >= PARALLEL_ACT_MIN_AGENTS ? 16 : 32);
+        h->stg_step = (h->crowd || c.num_agents > 8) ? 32 : tiles <= 2048 ? 64 : (c.num_agents >= 6 ? 16 : 32);
         if (const char *ev = tuning_env("MGRID_STAGE")) {  // tuning / test override
             const int v = atoi(ev);
-            if (!h->crowd && (v == 16 || v == 32 || v == 64)) h->stg_step = v;
+            if (!h->crowd && c.num_agents <= 8 && (v == 16 || v == 32 || v == 64)) h->stg_step = v;
         }
         h->lds_step = static_cast<size_t>(lds_for(ne, g, false, h->stg_step));
         if (h->lds_step > 64 * 1024) {  // does not fit: the default width
