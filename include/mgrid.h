@@ -257,6 +257,14 @@ int mg_stats(MgHandle h, int64_t *stats_dev, void *stream);
  * done.  Either pointer may be NULL. */
 int mg_agents_mask(MgHandle h, uint8_t *mask_dev, uint8_t *done_dev, void *stream);
 
+/* Diagnostic: which instantiations of the step / reset / gen_obs kernel this process has launched so far, as text in
+ * `buf` (HOST memory, `size` bytes, MG_EINVAL when too small): one line "V,SEE,MODE,WALLED,OH,MULTI,COMP,CROWD,STG:count"
+ * per instantiation - view size, see_through_walls, mode (0 step, 1 gen_obs, 2 reset), grids known to be ringed by
+ * walls, one-hot output, several steps per launch, CompetativeRedBlueDoor, cell-table act phase, staging width.
+ * No counterpart in the reference; the tests use it to prove that every compiled instantiation has been run against
+ * the oracle. */
+int mg_launch_census(char *buf, int32_t size);
+
 /* Per-environment episode statistics of a vector of environments after a step with MG_AUTORESET_SAME_STEP, by one
  * launch: replaces gym.wrappers.RecordEpisodeStatistics around every environment of the reference's SyncVectorEnv
  * (multigrid/scripts/train_ppo_cleanrl.py:173,366) and the `final_info` entries its training loop reads

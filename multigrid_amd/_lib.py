@@ -25,7 +25,7 @@ ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
            "mg_set_reward_schemes",
            "mg_reset", "mg_step", "mg_step_shards", "mg_step_n", "mg_gen_obs", "mg_gen_obs_of_state", "mg_get_state", "mg_set_state",
-           "mg_stats", "mg_episode_stats", "mg_agents_mask")
+           "mg_stats", "mg_episode_stats", "mg_agents_mask", "mg_launch_census")
 
 
 class MgConfig(ctypes.Structure):
@@ -184,11 +184,38 @@ def lib() -> ctypes.CDLL:
             L.mg_agents_mask.argtypes = [vp, vp, vp, vp]
         if hasattr(L, "mg_episode_stats"):
             L.mg_episode_stats.argtypes = [i32, i32] + [vp] * 9
+        if hasattr(L, "mg_launch_census"):
+            L.mg_launch_census.argtypes = [ctypes.c_char_p, i32]
         for name in EXPORTS:
             if name not in ("mg_last_error",) and hasattr(L, name):
                 getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def launch_census() -> dict:
+    """``{(V, SEE, MODE, WALLED, OH, MULTI, COMP, CROWD, STG): launches}`` of this process so far (``mg_launch_census``)."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib().mg_launch_census(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        what, n = line.split(":")
+        out[tuple(int(x) for x in what.split(","))] = int(n)
+    return out
+
+
+def compiled_instantiations() -> set:
+    """The instantiations of the tile kernel the library was built with, from the build's register report
+    (``kernel_registers.json``), as tuples like the keys of ``launch_census``."""
+    import json
+    import re
+    out = set()
+    for name in json.load(open(REGISTERS_PATH)):
+        m = re.search(r"mg_tile_kernel<([^>]*)>", name)
+        if m:
+            out.add(tuple({"true": 1, "false": 0}.get(x.strip(), None) if x.strip() in ("true", "false") else int(x)
+                          for x in m.group(1).split(",")))
+    return out
 
 
 class MgError(RuntimeError):

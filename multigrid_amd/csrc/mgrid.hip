@@ -42,6 +42,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <atomic>
 #include <mutex>
 
 #include "mgrid.h"
@@ -800,7 +801,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
 // CROWD: the kernel variant for 6 to 8 agents that may not overlap, where most steps have agents to compare: the
 // comparison goes through a cell-keyed table instead of over all pairs (kept out of the other variant, whose
 // code it would only lengthen).
-template <bool CROWD>
+// AQ: 2 or 4 when the environments have exactly that many agents - an environment then sits in (half) a quad of
+// lanes and its agents read each other's registers through quad permutes; 0: any number, through LDS.
+template <bool CROWD, int AQ = 0>
 __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int env0, int s0, int ns, int lane,
                                           int my_slot, int my_agent) {
     const int A = p.A();
@@ -911,6 +914,51 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         if (placed) reinterpret_cast<uint16_t *>(tbl)[pc] = 0;
         if (acts) reinterpret_cast<uint16_t *>(tbl)[ev.ci] = 0;
         wave_sync();
+    } else if (AQ != 0 && __ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+        // the same comparison as in the LDS form below, the other agents' words coming through quad permutes
+        // (lane ^ 1, and with four agents lane ^ 2 and lane ^ 3: all of them other agents of my environment)
+        const uint32_t my_pf = (r0.x & 0xFFFFu) | (ev.fxy << 16), my_pos = r0.x & 0xFFFFu;
+        const uint32_t occ_bits = EV_DROP | (p.overlap() ? 0u : EV_FWD);  // actions that ask who stands in front
+        const uint32_t try_occ = EV_TRY_DROP | (p.overlap() ? 0u : EV_TRY_FWD);
+        uint32_t o_pf[3], o_bits[3];
+#define MG_QUAD(x, ctrl) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), ctrl, 0xF, 0xF, false))
+        o_pf[0] = MG_QUAD(my_pf, 0xB1);  // quad_perm [1,0,3,2]
+        o_bits[0] = MG_QUAD(ev.bits, 0xB1);
+        if (AQ == 4) {
+            o_pf[1] = MG_QUAD(my_pf, 0x4E);  // [2,3,0,1]
+            o_bits[1] = MG_QUAD(ev.bits, 0x4E);
+            o_pf[2] = MG_QUAD(my_pf, 0x1B);  // [3,2,1,0]
+            o_bits[2] = MG_QUAD(ev.bits, 0x1B);
+        }
+        uint32_t rel[3];  // per partner: 1 it stands on the cell in front of me, 2 it faces the cell I face, 4 I stand in front of it
+#pragma unroll
+        for (int k = 0; k < AQ - 1; ++k) {
+            const bool at_front = (o_pf[k] & 0xFFFFu) == ev.fxy, same_front = (o_pf[k] >> 16) == ev.fxy;
+            const bool at_its_front = (o_pf[k] >> 16) == my_pos;
+            rel[k] = (at_front ? 1u : 0u) | (same_front ? 2u : 0u) | (at_its_front ? 4u : 0u);
+            occupied |= at_front;  // base.py:485,512: every agent counts, terminated ones included
+            unstable |= (ev.bits & EV_ONCELL) && same_front && (o_bits[k] & EV_MAY_WRITE);
+            clash |= need_occ && (o_bits[k] & EV_FWD) && (rel[k] & 3u);
+            clash |= (o_bits[k] & EV_ONCELL) && same_front && (ev.bits & EV_MAY_WRITE);
+            clash |= (o_bits[k] & occ_bits) && (ev.bits & EV_FWD) && (rel[k] & 6u);
+        }
+        clash |= unstable;
+        if (__ballot(unstable) != 0) {  // see the comment in the LDS form
+            const uint32_t un = unstable ? 1u : 0u;
+            uint32_t o_un[3];
+            o_un[0] = MG_QUAD(un, 0xB1);
+            if (AQ == 4) {
+                o_un[1] = MG_QUAD(un, 0x4E);
+                o_un[2] = MG_QUAD(un, 0x1B);
+            }
+#pragma unroll
+            for (int k = 0; k < AQ - 1; ++k) {
+                if (!o_un[k]) continue;
+                clash |= need_occ && (o_bits[k] & EV_TRY_FWD) && (rel[k] & 3u);
+                clash |= (o_bits[k] & try_occ) && (ev.bits & EV_FWD) && (rel[k] & 6u);
+            }
+        }
+#undef MG_QUAD
     } else if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
         if (mine) pair[lane] = make_uint2((r0.x & 0xFFFFu) | (ev.fxy << 16), ev.bits);
         wave_sync();
@@ -958,77 +1006,112 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         }
     }
     const uint64_t group = (A == 64 ? ~0ull : ((1ull << A) - 1ull)) << (my_slot * A);
+    const int kind = p.kind();
     finish_action(p, ev, r0, occupied);
     const bool final_here = mine && !clash;
-    const uint64_t writers = __ballot(final_here && (ev.bits & EV_WRITE)) & group;
-    uint64_t resync = __ballot(final_here && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE));  // blue-door toggles re-sync cell and object
+    // (what happens in few steps - cells written, goals reached, hook events - is first asked of the whole wavefront:
+    // the usual answer is "nowhere", and the per-environment questions are then never put)
     uint32_t *log = reinterpret_cast<uint32_t *>(lds + p.o.log) + (s0 + my_slot) * A;
-    int nlog = __popcll(writers);  // cells my environment has written so far
+    int nlog = 0;  // cells my environment has written so far
+    if (const uint64_t wr_any = __ballot(final_here && (ev.bits & EV_WRITE))) {
+        const uint64_t writers = wr_any & group;
+        nlog = __popcll(writers);
+        if (final_here && (ev.bits & EV_WRITE)) log[__popcll(writers & ((1ull << lane) - 1ull))] = ev.ci | (ev.nv << 16);
+    }
+    uint64_t resync = 0;  // blue-door toggles re-sync cell and object
+    if (kind == MG_KIND_REDBLUEDOORS) resync = __ballot(final_here && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE));
     // my agent after its action (marked agents: not yet)
     uint2 row = final_here ? ev.r : r0;
     uint32_t my_term = (r0.x >> 24) | ((final_here && (ev.bits & EV_TERM)) ? 1u : 0u);
     bool my_goal = final_here && (ev.bits & EV_GOAL);
-    if (final_here) {
-        if ((ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
-        if (ev.bits & EV_WRITE) log[__popcll(writers & ((1ull << lane) - 1ull))] = ev.ci | (ev.nv << 16);
-    }
+    if (final_here && (ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
     const uint64_t left = __ballot(clash);  // marked agents: they act one by one, in the order of base.py:457-464
     const bool replayed = (left & group) != 0;
     if (left != 0) {
         uint8_t *ordb = lds + p.o.ord + (s0 + my_slot) * A;
-        if (p.order == nullptr) {  // the environment's order of this step, drawn once per environment: see order_key()
-            if (replayed && my_agent == 0) {
+        int pos = -1;  // my agent's place in the order
+        if (AQ != 0) {
+            // two or four agents: every marked lane holds its environment's order in a register (given, or drawn as
+            // order_key() says: every lane of the environment draws the same)
+            uint32_t ordw;
+            if (p.order != nullptr) {
+                ordw = AQ == 4 ? *reinterpret_cast<const uint32_t *>(ordb) : *reinterpret_cast<const uint16_t *>(ordb);
+            } else {
                 const uint2 hs = *reinterpret_cast<const uint2 *>(h);  // step_count, episode
                 const uint32_t key = order_key(p, env0 + s0 + my_slot, hs.y, static_cast<int>(hs.x) + 1);
                 uint32_t word = 0;
-                if (A <= 8) {
-                    uint64_t ordw = 0x0706050403020100ull;
-#pragma unroll 1
-                    for (int k = A - 1, f = 0; k > 0; --k, ++f) {
-                        const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
-                        const uint64_t d = ((ordw >> (8 * k)) ^ (ordw >> (8 * j))) & 0xFF;
-                        ordw ^= (d << (8 * k)) ^ (d << (8 * j));
-                    }
-#pragma unroll 1
-                    for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(ordw >> (8 * k));
-                } else {
-#pragma unroll 1
-                    for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
-#pragma unroll 1
-                    for (int k = A - 1, f = 0; k > 0; --k, ++f) {
-                        const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
-                        const uint8_t t = ordb[k];
-                        ordb[k] = ordb[j];
-                        ordb[j] = t;
-                    }
+                ordw = 0x03020100u;
+#pragma unroll
+                for (int k = AQ - 1, f = 0; k > 0; --k, ++f) {
+                    const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                    const uint32_t d = ((ordw >> (8 * k)) ^ (ordw >> (8 * j))) & 0xFF;
+                    ordw ^= (d << (8 * k)) ^ (d << (8 * j));
                 }
             }
-            wave_sync();
-        }
-        int pos = -1;  // my agent's place in the order
-        if (clash) {
+#pragma unroll
+            for (int n = AQ - 1; n >= 0; --n)
+                if (((ordw >> (8 * n)) & 0xFF) == static_cast<uint32_t>(my_agent)) pos = n;
+        } else {
+            if (p.order == nullptr) {  // the environment's order of this step, drawn once per environment: see order_key()
+                if (replayed && my_agent == 0) {
+                    const uint2 hs = *reinterpret_cast<const uint2 *>(h);  // step_count, episode
+                    const uint32_t key = order_key(p, env0 + s0 + my_slot, hs.y, static_cast<int>(hs.x) + 1);
+                    uint32_t word = 0;
+                    if (A <= 8) {
+                        uint64_t ordw = 0x0706050403020100ull;
 #pragma unroll 1
-            for (int n = A - 1; n >= 0; --n)
-                if (ordb[n] == my_agent) pos = n;
+                        for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                            const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                            const uint64_t d = ((ordw >> (8 * k)) ^ (ordw >> (8 * j))) & 0xFF;
+                            ordw ^= (d << (8 * k)) ^ (d << (8 * j));
+                        }
+#pragma unroll 1
+                        for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(ordw >> (8 * k));
+                    } else {
+#pragma unroll 1
+                        for (int k = 0; k < A; ++k) ordb[k] = static_cast<uint8_t>(k);
+#pragma unroll 1
+                        for (int k = A - 1, f = 0; k > 0; --k, ++f) {
+                            const int j = static_cast<int>((order_field(key, f, word) * static_cast<uint32_t>(k + 1)) >> 16);
+                            const uint8_t t = ordb[k];
+                            ordb[k] = ordb[j];
+                            ordb[j] = t;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+            if (clash) {
+#pragma unroll 1
+                for (int n = A - 1; n >= 0; --n)
+                    if (ordb[n] == my_agent) pos = n;
+            }
         }
         if (resync & group) flags &= ~FLAG_STALE;
+        uint64_t acted = 0;  // marked agents that have had their turn
 #pragma unroll 1
         for (int n = 0; n < A; ++n) {  // base.py:464
             const bool turn = clash && pos == n;
-            if (__ballot(turn) == 0) continue;
+            const uint64_t now = __ballot(turn);
+            if (now == 0) continue;
             if (turn) {
-                uint32_t w = w0;  // the cell in front as the agents before me have left it
+                // The first marked agent of an environment acts on the state the step began with (what the unmarked
+                // agents did does not concern it): its evaluation from above stands.  The others see what the marked
+                // agents before them have done.
+                if (acted & group) {
+                    uint32_t w = w0;  // the cell in front as the agents before me have left it
 #pragma unroll 1
-                for (int j = 0; j < nlog; ++j) {
-                    const uint32_t e = log[j];
-                    if ((e & 0xFFFF) == ev.ci) w = e >> 16;
+                    for (int j = 0; j < nlog; ++j) {
+                        const uint32_t e = log[j];
+                        if ((e & 0xFFFF) == ev.ci) w = e >> 16;
+                    }
+                    ev = eval_action(p, r0, w, my_act, flags, blue_xy);
+                    bool occ = false;  // base.py:485,512: every agent counts, terminated ones included
+                    if (needs_occupancy(p, ev))
+#pragma unroll 1
+                        for (int k = 0; k < A; ++k) occ |= *reinterpret_cast<const uint16_t *>(h + H_ROWS + 8 * k) == ev.fxy;
+                    finish_action(p, ev, r0, occ);
                 }
-                ev = eval_action(p, r0, w, my_act, flags, blue_xy);
-                bool occ = false;  // base.py:485,512: every agent counts, terminated ones included
-                if (needs_occupancy(p, ev))
-#pragma unroll 1
-                    for (int k = 0; k < A; ++k) occ |= *reinterpret_cast<const uint16_t *>(h + H_ROWS + 8 * k) == ev.fxy;
-                finish_action(p, ev, r0, occ);
                 if (ev.bits & EV_ALIVE) {
                     if (ev.r.x != r0.x || ev.r.y != r0.y) *reinterpret_cast<uint2 *>(a) = ev.r;
                     row = ev.r;
@@ -1037,10 +1120,13 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                 if (ev.bits & EV_TERM) my_term = 1;
                 my_goal = (ev.bits & EV_GOAL) != 0;
             }
+            acted |= now;
             if (__ballot(turn && (ev.bits & EV_WRITE)) & group) ++nlog;
-            const uint64_t rs = __ballot(turn && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE));
-            resync |= rs;
-            if (rs & group) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+            if (kind == MG_KIND_REDBLUEDOORS) {
+                const uint64_t rs = __ballot(turn && (ev.bits & EV_FLIP) && (ev.bits & EV_BLUE));
+                resync |= rs;
+                if (rs & group) flags &= ~FLAG_STALE;  // grid.update re-syncs cell and object
+            }
             wave_sync();  // the next round sees this round's rows and cells
         }
     }
@@ -1056,7 +1142,6 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     //   RedBlueDoors         agents toggling towards the open blue door: success for each of them while the red door
     //                        is open, else failure for the first, which re-closes the door OBJECT and so ends the
     //                        matter for the others (redbluedoors.py:176-185).
-    const int kind = p.kind();
     // the cell a toggling agent faces as the step leaves it (a toggle neither moves nor turns the agent)
     auto cell_at_end = [&](uint32_t ci, uint32_t at_start) {
         uint32_t w = at_start;
@@ -1068,66 +1153,75 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         return w;
     };
     const bool toggles = mine && my_act == ACT_TOGGLE;
-    const bool faces_cell = (ev.fxy & 0xFF) < static_cast<uint32_t>(p.W()) && (ev.fxy >> 8) < static_cast<uint32_t>(p.H());
     const uint4 h0 = *reinterpret_cast<const uint4 *>(h);  // step_count | episode | flags | meta
     const int step = static_cast<int>(h0.x) + 1;           // base.py:395
     const uint32_t was_over = h0.z & FLAG_OVER;
-    const uint64_t goals = __ballot(mine && my_goal) & group;
-    uint32_t my_tout = my_term;                                                     // base.py:400
-    uint32_t my_rewm = p.joint() ? (goals ? 1u : 0u) : (my_goal ? 1u : 0u);         // base.py:558-562
+    uint32_t my_tout = my_term;                  // base.py:400
+    uint32_t my_rewm = my_goal ? 1u : 0u;        // base.py:558-562
+    if (p.joint())
+        if (const uint64_t goals = __ballot(mine && my_goal)) my_rewm = (goals & group) ? 1u : 0u;
     bool hook_term = false;  // the hook terminated my agent (its own flag too, not only the returned one)
     if (kind == MG_KIND_BLOCKEDUNLOCKPICKUP) {
         const bool carrier = mine && (row.y & 0xFF) == T_BOX;
-        if (__ballot(carrier) & group) {  // on_success, base.py:535-562
-            hook_term = p.succ_any() || carrier;
-            if (hook_term) my_tout = 1;
-            if (p.joint() || carrier) my_rewm = 1;
+        if (const uint64_t carriers = __ballot(carrier)) {
+            if (carriers & group) {  // on_success, base.py:535-562
+                hook_term = p.succ_any() || carrier;
+                if (hook_term) my_tout = 1;
+                if (p.joint() || carrier) my_rewm = 1;
+            }
         }
     } else if (kind == MG_KIND_LOCKEDHALLWAY) {
         uint32_t lh_bit = 0;  // colour bit of the unlocked door I toggle towards
-        if (toggles && faces_cell) {
+        if (toggles && (ev.fxy & 0xFF) < static_cast<uint32_t>(p.W()) && (ev.fxy >> 8) < static_cast<uint32_t>(p.H())) {
             const uint32_t wa = cell_at_end(ev.ci, w0);
             if ((wa & 15) == T_DOOR && ((wa >> 4) & 15) != S_LOCKED) lh_bit = (1u << ((wa >> 8) & 7)) & FLAG_LH_MASK;
         }
-        uint32_t newbits = 0, first = 0;
+        if (__ballot(lh_bit != 0)) {
+            uint32_t newbits = 0, first = 0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const uint64_t m = __ballot(lh_bit == (1u << c)) & group;
-            if (m != 0 && !(flags & (1u << c))) {
-                newbits |= 1u << c;
-                if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+            for (int c = 0; c < 6; ++c) {
+                const uint64_t m = __ballot(lh_bit == (1u << c)) & group;
+                if (m != 0 && !(flags & (1u << c))) {
+                    newbits |= 1u << c;
+                    if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+                }
             }
+            my_rewm += p.joint() ? static_cast<uint32_t>(__popc(newbits)) : first;  // `+=`, locked_hallway.py:207-211
+            flags |= newbits;
         }
-        my_rewm += p.joint() ? static_cast<uint32_t>(__popc(newbits)) : first;  // `+=`, locked_hallway.py:207-211
-        flags |= newbits;
         if (__popc(flags & FLAG_LH_MASK) == p.num_rooms()) my_tout = 1;  // only the returned dict, :213-215
     } else if (kind == MG_KIND_REDBLUEDOORS) {
         const bool cand = toggles && ev.fxy == blue_xy;
-        const uint64_t cands = __ballot(cand) & group;
-        if (cands) {
-            const uint16_t *fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
-            const uint32_t wb = cell_at_end((blue_xy & 0xFF) * p.H() + (blue_xy >> 8), fcv[A + 1]);
-            const uint32_t wr = cell_at_end((red_xy & 0xFF) * p.H() + (red_xy >> 8), fcv[A]);
-            const int so = (flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
-            if ((wb & 15) == T_DOOR && so == S_OPEN) {
-                if (((wr >> 4) & 15) == S_OPEN) {  // on_success for every one of them, base.py:535-562
-                    hook_term = p.succ_any() || cand;
-                    if (p.joint() || cand) my_rewm = 1;
-                } else {  // on_failure for the first, base.py:564-585
-                    hook_term = p.fail_any() || (cand && __builtin_ctzll(cands) == lane);
-                    flags |= FLAG_STALE;
+        if (const uint64_t cands_any = __ballot(cand)) {
+            const uint64_t cands = cands_any & group;
+            if (cands) {
+                const uint16_t *fcv = reinterpret_cast<const uint16_t *>(h + p.HFC);
+                const uint32_t wb = cell_at_end((blue_xy & 0xFF) * p.H() + (blue_xy >> 8), fcv[A + 1]);
+                const uint32_t wr = cell_at_end((red_xy & 0xFF) * p.H() + (red_xy >> 8), fcv[A]);
+                const int so = (flags & FLAG_STALE) ? S_CLOSED : static_cast<int>((wb >> 4) & 15);
+                if ((wb & 15) == T_DOOR && so == S_OPEN) {
+                    if (((wr >> 4) & 15) == S_OPEN) {  // on_success for every one of them, base.py:535-562
+                        hook_term = p.succ_any() || cand;
+                        if (p.joint() || cand) my_rewm = 1;
+                    } else {  // on_failure for the first, base.py:564-585
+                        hook_term = p.fail_any() || (cand && __builtin_ctzll(cands) == lane);
+                        flags |= FLAG_STALE;
+                    }
+                    if (hook_term) my_tout = 1;
                 }
-                if (hook_term) my_tout = 1;
             }
         }
     }
     {
-        const bool all_term = (__ballot(mine && my_tout != 0) & group) == group;
+        bool all_term = false;
+        if (const uint64_t touts = __ballot(mine && my_tout != 0)) all_term = (touts & group) == group;
         const bool trunc = step >= p.max_steps;  // base.py:401-402
         const bool over = trunc || all_term;
         const bool will_reset = over && p.autoreset() != MG_AUTORESET_NONE;
-        const int paid = __popcll(__ballot(mine && (my_rewm & 1)) & group) + 2 * __popcll(__ballot(mine && (my_rewm & 2)) & group) +
-                         4 * __popcll(__ballot(mine && (my_rewm & 4)) & group);
+        int paid = 0;
+        if (__ballot(mine && my_rewm != 0))
+            paid = __popcll(__ballot(mine && (my_rewm & 1)) & group) + 2 * __popcll(__ballot(mine && (my_rewm & 2)) & group) +
+                   4 * __popcll(__ballot(mine && (my_rewm & 4)) & group);
         if (mine) {
             lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>(my_term);  // what gen_obs sees (base.py:399)
             lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_tout);
@@ -1708,12 +1802,30 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             }
         } else {
 #pragma unroll 1
-            for (int s0 = 0; s0 < net; s0 += NE) act_lanes<CROWD>(p, lds, e0, s0, min(NE, net - s0), lane, my_slot, my_agent);
+            for (int s0 = 0; s0 < net; s0 += NE) {
+                const int ns = min(NE, net - s0);
+                // (the quad-permute forms serve the small rooms of BlockedUnlockPickup / LockedHallway / RedBlueDoors,
+                // whose agents meet all the time; see-through kernels - open Empty rooms - keep to the one general form)
+                if (!CROWD && !SEE && A == 2) act_lanes<false, 2>(p, lds, e0, s0, ns, lane, my_slot, my_agent);
+                else if (!CROWD && !SEE && A == 4) act_lanes<false, 4>(p, lds, e0, s0, ns, lane, my_slot, my_agent);
+                else act_lanes<CROWD>(p, lds, e0, s0, ns, lane, my_slot, my_agent);
+            }
         }
         wave_sync();
+        MG_EXP(MG_TICK(ta1);)
         MG_STAMP(2);
         prefetch_actions();
         restart_now(0, net);
+        // (diagnostic builds: staging, act, same-step restarts)
+        MG_EXP(
+        MG_TICK(ta2);
+        if (p.dbg_buf && (p.dbg & 16) && threadIdx.x == 0) {
+            unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32 + 20;
+            d[0] = ta0 - tstart;
+            d[1] = ta1 - ta0;
+            d[2] = ta2 - ta1;
+        }
+        )
     }
 
     MG_STAMP(3);
@@ -2534,8 +2646,25 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 //     launch with the staging width picked for the batch (16 / 32 / 64) - each for walled and for general grids;
 //   launches of any mode that also write one-hot images (bound by those stores: general border code);
 //   reset and gen_obs launches, walled or general.
+// Which instantiations this process has launched so far (mg_launch_census): every launch_k<> owns one counter,
+// linked into a list the first time it is used.
+struct LaunchCount {
+    const char *what;  // the template arguments, "V,SEE,MODE,WALLED,OH,MULTI,COMP,CROWD,STG"
+    std::atomic<long> n{0};
+    LaunchCount *next = nullptr;
+};
+std::atomic<LaunchCount *> g_launch_counts{nullptr};
+
 template <int V, bool SEE, int MODE, bool WALLED, bool OH, bool MULTI, bool COMP, bool CROWD, int STG>
 void launch_k(const MgEnv *h, const KParams &kp, size_t lds, hipStream_t s) {
+    static char what[48];
+    static LaunchCount count;
+    if (count.n.fetch_add(1, std::memory_order_relaxed) == 0) {
+        snprintf(what, sizeof what, "%d,%d,%d,%d,%d,%d,%d,%d,%d", V, SEE, MODE, WALLED, OH, MULTI, COMP, CROWD, STG);
+        count.what = what;
+        count.next = g_launch_counts.load(std::memory_order_relaxed);
+        while (!g_launch_counts.compare_exchange_weak(count.next, &count, std::memory_order_release, std::memory_order_relaxed)) {}
+    }
     hipLaunchKernelGGL((mg_tile_kernel<V, SEE, MODE, WALLED, OH, MULTI, COMP, CROWD, STG>), dim3(h->num_tiles), dim3(64), lds, s, kp);
 }
 
@@ -3323,6 +3452,19 @@ int mg_episode_stats(int32_t num_envs, int32_t num_agents, const float *reward_d
                        done_dev, episode_return_dev, episode_length_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MG_EHIP, "mg_episode_stats: %s", hipGetErrorString(e));
+    return MG_OK;
+}
+
+int mg_launch_census(char *buf, int32_t size) {
+    if (!buf || size < 1) return MG_EINVAL;
+    std::string out;
+    for (const LaunchCount *c = g_launch_counts.load(std::memory_order_acquire); c; c = c->next) {
+        char line[96];
+        snprintf(line, sizeof line, "%s:%ld\n", c->what, c->n.load(std::memory_order_relaxed));
+        out += line;
+    }
+    if (static_cast<int>(out.size()) + 1 > size) return MG_EINVAL;
+    memcpy(buf, out.c_str(), out.size() + 1);
     return MG_OK;
 }
 

@@ -361,16 +361,13 @@ def test_explicit_tile_shapes(case, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("stage", ["16", "32", "64"])
-@pytest.mark.parametrize("case,lanes", [("cfg3", None), ("cfg4", None), ("cfg5", None), ("cfg2", "0"), ("cfg2", "1"),
-                                        ("cfg3", "1"), ("cfg4", "1"), ("odd3", None), ("single", None)])
-def test_staging_widths_and_act_forms(case, lanes, stage, monkeypatch):
-    """The step kernel's variants that the library otherwise picks by batch size and kind: images staged 16, 32 or 64
-    agents at a time (MGRID_STAGE), and the act phase started with one lane per agent or per environment
-    (MGRID_LANES_ACT).  Same contract as everywhere: bit-exact against the C oracle, same-step auto-reset."""
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg4", "cfg5", "odd3", "single"])
+def test_staging_widths(case, stage, monkeypatch):
+    """The step kernel's variants that the library otherwise picks by batch size: images staged 16, 32 or 64 agents at
+    a time (MGRID_STAGE).  Same contract as everywhere: bit-exact against the C oracle, next-step auto-reset."""
+    lanes = None
     monkeypatch.setenv("MGRID_TUNING", "1")
     monkeypatch.setenv("MGRID_STAGE", stage)
-    if lanes is not None:
-        monkeypatch.setenv("MGRID_LANES_ACT", lanes)
     e = 777
     spec, pool, env, ora = make(case, e, autoreset=2)
     a, n_l = spec["num_agents"], len(pool[0])

@@ -26,6 +26,13 @@ def run(cfg, agents, e, **kw):
     torch.cuda.synchronize()
     b = buf[:nt.value].cpu().numpy().astype(np.float64)
     total = (b[:, 10] - b[:, 0]).mean()
+    if total > 0:  # when do wavefronts start and end, relative to the first start (one clock domain assumed)
+        t0 = b[:, 0].min()
+        st, en, life = b[:, 0] - t0, b[:, 10] - t0, b[:, 10] - b[:, 0]
+        q = lambda x: " / ".join(f"{np.percentile(x, p):.0f}" for p in (0, 50, 90, 99, 100))
+        print(f"   start  (min / median / p90 / p99 / max): {q(st)} clk")
+        print(f"   end    (min / median / p90 / p99 / max): {q(en)} clk")
+        print(f"   life   (min / median / p90 / p99 / max): {q(life)} clk")
     print(f"{cfg} A={agents} E={e} tiles={nt.value} tile={os.environ.get('MGRID_TILE','auto')}: mean wave lifetime {total:.0f} clk")
     prev = 0
     for k in range(1, 11):
@@ -34,11 +41,9 @@ def run(cfg, agents, e, **kw):
         prev = k
     if int(os.environ.get("MGRID_DBG", "0")) & 16:
         n = b[:, 19].sum()
-        print(f"   light ticks per wave: staging {b[:,20].mean():.0f}  act/agent lanes {b[:,21].mean():.0f}  act/env lanes {b[:,22].mean():.0f}  whole {b[:,23].mean():.0f} clk")
-        print(f"   act end -> first pass {b[:,29].mean():.0f}  start -> scalars written {b[:,31].mean():.0f}  then to the end {b[:,30].mean():.0f} clk")
-        print(f"   in-order act: setup {b[:,25].mean():.0f}  actions {b[:,26].mean():.0f}  hooks {b[:,27].mean():.0f}  tail {b[:,28].mean():.0f} clk")
-        print(f"   replayed environments: {b[:,24].sum():.0f} of {e} in {(b[:,24] > 0).sum()} of {nt.value} tiles")
-        print(f"   light ticks per pass: compute {b[:,16].sum()/n:.0f}  commit {b[:,17].sum()/n:.0f}  copy-out {b[:,18].sum()/n:.0f} clk ({n:.0f} passes)")
+        print(f"   light ticks per wave: staging {b[:,20].mean():.0f}  act {b[:,21].mean():.0f}  same-step restarts {b[:,22].mean():.0f}  whole {b[:,23].mean():.0f} clk")
+        print(f"   start -> scalars written {b[:,31].mean():.0f}  then to the end {b[:,30].mean():.0f} clk")
+        print(f"   light ticks per pass: grids+patch+log+front+draw+observe {b[:,16].sum()/n:.0f}  commit {b[:,17].sum()/n:.0f}  copy-out {b[:,18].sum()/n:.0f}  act inside the pass {b[:,20+0].sum()*0 + b[:,16+4].sum()*0:.0f} clk ({n:.0f} passes)")
     env.close()
 
 if __name__ == "__main__":
