@@ -266,11 +266,14 @@ __device__ __forceinline__ int udiv(int n, uint32_t magic) {
     return magic ? static_cast<int>(__umulhi(static_cast<uint32_t>(n), magic)) : n;
 }
 
+// layout of episode `episode` of environment `env`: (env_id_offset + env + 7919 * episode) mod N
 __device__ __forceinline__ int pick_layout(const KParams &p, int env, uint32_t episode) {
     // (restarts are rare: both numbers are fetched here rather than kept for the whole step)
-    return static_cast<int>((static_cast<uint64_t>(late_arg<uint32_t>(offsetof(KParams, env_offset))) + static_cast<uint64_t>(env) +
-                             static_cast<uint64_t>(LAYOUT_STRIDE) * episode) %
-                            static_cast<uint64_t>(late_arg<int>(offsetof(KParams, num_layouts))));
+    const uint32_t n = static_cast<uint32_t>(late_arg<int>(offsetof(KParams, num_layouts)));
+    const uint32_t g = late_arg<uint32_t>(offsetof(KParams, env_offset)) + static_cast<uint32_t>(env);  // both below 2^31
+    if (n <= 0xFFFFu)  // the same residue from 32-bit pieces: a 64-bit remainder is a long software loop
+        return static_cast<int>((g % n + (episode % n) * (LAYOUT_STRIDE % n)) % n);
+    return static_cast<int>((static_cast<uint64_t>(g) + static_cast<uint64_t>(LAYOUT_STRIDE) * episode) % static_cast<uint64_t>(n));
 }
 
 // On-device agent order (used when the caller passes no order): a Fisher-Yates shuffle of
@@ -1266,20 +1269,33 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
 
 // Replace one environment's header in LDS and its grid in HBM by a start state from the pool
 // (MultiGridEnv.reset, multigrid/base.py:310-362, with the layout precomputed on the host).
-// Executed by the whole wavefront for one environment at a time.
+// Executed by the whole wavefront for one environment at a time.  `lds_grid`: where the environment's grid lies in
+// LDS when it is there already (it then takes the new grid too), else null.  Header block and grid are asked for
+// together and answered by one trip to memory.
 __device__ __forceinline__ void reload_env(const KParams &p, uint8_t *lds, int slot, int env, int layout,
-                                           uint32_t episode, int lane) {
+                                           uint32_t episode, int lane, uint8_t *lds_grid) {
     // (restarts are rare: the pool's addresses are fetched here rather than kept for the whole step)
     const uint4 *sh = reinterpret_cast<const uint4 *>(late_arg<const uint8_t *>(offsetof(KParams, pool_hdr)) + static_cast<size_t>(layout) * p.HS);
     const uint4 *sg = reinterpret_cast<const uint4 *>(late_arg<const uint8_t *>(offsetof(KParams, pool_grid)) + static_cast<size_t>(layout) * p.GS);
     uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr + slot * p.HP);
-    uint4 *gg = reinterpret_cast<uint4 *>(p.grid + static_cast<size_t>(env) * p.GS);
-    for (int i = lane; i < p.HS / 16; i += 64) {
-        uint4 v = sh[i];
-        if (i == 0) v.y = episode;  // keep the environment's own episode counter
-        dh[i] = v;
+    uint4 *gg = reinterpret_cast<uint4 *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(env) * p.GS);
+    uint4 *lg = reinterpret_cast<uint4 *>(lds_grid);
+    const int nh = p.HS / 16, ng = p.GS / 16;  // (a header block has at most 42 pieces: one per lane)
+    uint4 hv = make_uint4(0u, 0u, 0u, 0u), gv = hv;
+    if (lane < nh) hv = sh[lane];
+    if (lane < ng) gv = sg[lane];
+    if (lane == 0) hv.y = episode;  // keep the environment's own episode counter
+    if (lane < nh) dh[lane] = hv;
+    if (lane < ng) {
+        gg[lane] = gv;
+        if (lg) lg[lane] = gv;
     }
-    for (int i = lane; i < p.GS / 16; i += 64) gg[i] = sg[i];
+#pragma unroll 1
+    for (int i = 64 + lane; i < ng; i += 64) {
+        const uint4 v = sg[i];
+        gg[i] = v;
+        if (lg) lg[i] = v;
+    }
 }
 
 // ---- observe: one lane per agent ------------------------------------------------------------------
@@ -1608,20 +1624,6 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
 #pragma unroll 1
         for (int i = lane; i < n16_; i += 64) dg_[i + gpq * udiv(i, p.magic_per)] = src_[i];
     };
-    auto patch_all_grids = [&]() {  // environments restarted since the last patch: their grid comes from the pool
-        if (__ballot(lane < net && lsrc[lane] >= 0)) {
-            const uint8_t *pool_grid_ = late_arg<const uint8_t *>(offsetof(KParams, pool_grid));
-            const int n16_ = net * per;
-            uint4 *dg_ = reinterpret_cast<uint4 *>(lds + p.o.grid);
-#pragma unroll 1
-            for (int i = lane; i < n16_; i += 64) {
-                const int sub = udiv(i, p.magic_per);
-                const int src = lsrc[sub];
-                if (src >= 0)
-                    dg_[i + gpq * sub] = reinterpret_cast<const uint4 *>(pool_grid_ + static_cast<size_t>(src) * p.GS)[i - sub * per];
-            }
-        }
-    };
 #undef MG_ISSUE1
 #undef MG_COMMIT1
 #undef MG_EACH
@@ -1699,7 +1701,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         while (m) {
             const int s = __builtin_ctzll(m);
             m &= m - 1;
-            reload_env(p, lds, s, e0 + s, __shfl(layout, s), __shfl(episode, s), lane);
+            reload_env(p, lds, s, e0 + s, __shfl(layout, s), __shfl(episode, s), lane, nullptr);
         }
         wave_sync();
     }
@@ -1770,7 +1772,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     };
     // MG_AUTORESET_SAME_STEP: environments [first, first + count) of the tile whose episode ended in this step take
     // their next start state now, before the views are made
-    auto restart_now = [&](int first, int count) {
+    // (`resident`: environments below this slot have their grids in LDS already; the others' are marked for patch())
+    auto restart_now = [&](int first, int count, int resident) {
         if (p.autoreset() != MG_AUTORESET_SAME_STEP) return;
         uint64_t m = __ballot(lane >= first && lane < first + count && lds[p.o.flag + 4 * lane + 1] != 0);
         if (m) {
@@ -1781,8 +1784,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HP + H_EPISODE) + 1u;
                 const int layout = pick_layout(p, env, episode);
                 wave_sync();
-                reload_env(p, lds, s, env, layout, episode, lane);
-                if (lane == 0) lsrc[s] = layout;
+                reload_env(p, lds, s, env, layout, episode, lane, s < resident ? lds + p.o.grid + s * p.GP : nullptr);
+                if (lane == 0 && s >= resident) lsrc[s] = layout;
                 if (lane == 0) lds[p.o.flag + 4 * s + 2] = 0;  // the fresh grid takes no patches
                 if (lane == 0) lds[p.o.flag + 4 * s + 3] = 0;
                 wave_sync();
@@ -1815,7 +1818,13 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         MG_EXP(MG_TICK(ta1);)
         MG_STAMP(2);
         prefetch_actions();
-        restart_now(0, net);
+        // the first sub-tile's grids, on their way since the launch began, land in LDS now: environments that restart
+        // put their new grid there themselves
+        if (!MULTI && passes) {
+            commit(0);
+            wave_sync();
+        }
+        restart_now(0, net, MULTI ? net : min(NE, net));
         // (diagnostic builds: staging, act, same-step restarts)
         MG_EXP(
         MG_TICK(ta2);
@@ -1847,16 +1856,16 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             if (MODE == MODE_STEP && !ACT_FIRST) {
                 act_lanes<false>(p, lds, e0, s0, ns, lane, my_slot, my_agent);
                 if (s0 == 0) prefetch_actions();
-                restart_now(s0, ns);
+                restart_now(s0, ns, MULTI ? net : 0);
             }
             MG_EXP(MG_TICK(tka);)
             // the sub-tile's grids: the first ones were set out when the launch began, the others came in at the
             // end of the pass before; what was restarted in this launch is taken from the pool
-            if (!MULTI && s0 == 0) {
+            if (!MULTI && s0 == 0 && !(MODE == MODE_STEP && ACT_FIRST)) {
                 if (MODE == MODE_RESET) issue(0);
                 commit(0);
             }
-            patch(s0, gslot0);
+            if (!MULTI && !(MODE == MODE_STEP && ACT_FIRST && s0 == 0)) patch(s0, gslot0);
             wave_sync();
             if (s0 == 0) MG_STAMP(4);
             const bool mine = lane < np && ((sub_mask >> my_slot) & 1);
@@ -2095,33 +2104,46 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     }
 
     // ---- per-agent scalars: one coalesced element per lane ---------------------------------------------
+    // (every pointer is fetched, and every value read from LDS, before the first store goes out: one wait for each
+    // kind of memory instead of one per output)
     uint8_t *out_direction = p.direction, *out_terminated = p.terminated, *out_truncated = p.truncated;
     float *out_reward = p.reward;
-    if constexpr (!MULTI) {  // (the multi-step kernel moves these pointers on from step to step)
+    uint2 *out_rows = nullptr;      // optional outputs of single-step launches (callers that mirror one environment
+    double *out_reward64 = nullptr;  // on the host)
+    if constexpr (!MULTI) {  // (the multi-step kernel moves its pointers on from step to step)
         out_direction = late_arg<uint8_t *>(offsetof(KParams, direction));
         out_reward = late_arg<float *>(offsetof(KParams, reward));
         out_terminated = late_arg<uint8_t *>(offsetof(KParams, terminated));
         out_truncated = late_arg<uint8_t *>(offsetof(KParams, truncated));
+        out_rows = late_arg<uint2 *>(offsetof(KParams, rows_out));
+        out_reward64 = late_arg<double *>(offsetof(KParams, reward64));
     }
     for (int s = lane; s < nag; s += 64) {
         const int slot = udiv(s, p.magic_a);
         if (!((active_mask >> slot) & 1)) continue;
         const size_t o = static_cast<size_t>(e0) * A + s;
-        if (out_direction) out_direction[o] = lds[p.o.hdr + slot * p.HP + H_ROWS + 8 * (s - slot * A) + R_DIR];
+        const uint2 row = *reinterpret_cast<const uint2 *>(lds + p.o.hdr + slot * p.HP + H_ROWS + 8 * (s - slot * A));
+        uint32_t tout = 0, trunc = 0, m = 0;
+        double R = 0.0;
         if (MODE == MODE_STEP) {
-            if (out_reward)
-                out_reward[o] = COMP ? static_cast<float>(reinterpret_cast<const double *>(lds + p.o.racc)[s])
-                                     : static_cast<float>(reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]));
-            if (out_terminated) out_terminated[o] = lds[p.o.tout + s];
-            if (out_truncated) out_truncated[o] = lds[p.o.flag + 4 * slot];
+            tout = lds[p.o.tout + s];
+            trunc = lds[p.o.flag + 4 * slot];
+            if (COMP) {
+                R = reinterpret_cast<const double *>(lds + p.o.racc)[s];
+            } else {
+                m = lds[p.o.rewm + s];
+                R = reinterpret_cast<const double *>(lds + p.o.R)[slot];
+            }
         }
-        if constexpr (!MULTI) {  // optional outputs of single-step launches (callers that mirror one environment on the host)
-            if (uint2 *out_rows = late_arg<uint2 *>(offsetof(KParams, rows_out)))
-                out_rows[o] = *reinterpret_cast<const uint2 *>(lds + p.o.hdr + slot * p.HP + H_ROWS + 8 * (s - slot * A));
-            if (MODE == MODE_STEP)
-                if (double *out_reward64 = late_arg<double *>(offsetof(KParams, reward64)))
-                    out_reward64[o] = COMP ? reinterpret_cast<const double *>(lds + p.o.racc)[s]
-                                           : reward_times(reinterpret_cast<const double *>(lds + p.o.R)[slot], lds[p.o.rewm + s]);
+        asm volatile("" : "+v"(tout), "+v"(trunc), "+v"(m));  // all of the above before any of the below
+        if (out_direction) out_direction[o] = static_cast<uint8_t>(row.x >> 16);
+        if (out_rows) out_rows[o] = row;
+        if (MODE == MODE_STEP) {
+            const double r = COMP ? R : (m == 0 ? 0.0 : reward_times(R, static_cast<int>(m)));
+            if (out_reward) out_reward[o] = static_cast<float>(r);
+            if (out_reward64) out_reward64[o] = r;
+            if (out_terminated) out_terminated[o] = static_cast<uint8_t>(tout);
+            if (out_truncated) out_truncated[o] = static_cast<uint8_t>(trunc);
         }
     }
 
@@ -2138,14 +2160,9 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
                 const uint32_t episode = *reinterpret_cast<const uint32_t *>(lds + p.o.hdr + s * p.HP + H_EPISODE) + 1u;
                 wave_sync();
                 const int layout = pick_layout(p, env, episode);
-                reload_env(p, lds, s, env, layout, episode, lane);
-                if (MULTI && lane == 0) lsrc[s] = layout;
+                reload_env(p, lds, s, env, layout, episode, lane, MULTI ? lds + p.o.grid + s * p.GP : nullptr);  // (the grids kept in LDS follow)
             }
             wave_sync();
-            if (MULTI) {  // the grids kept in LDS follow
-                patch_all_grids();
-                wave_sync();
-            }
         }
     }
     if constexpr (MULTI) {  // on to the next step's slices of the inputs and outputs
