@@ -917,7 +917,8 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         if (placed) reinterpret_cast<uint16_t *>(tbl)[pc] = 0;
         if (acts) reinterpret_cast<uint16_t *>(tbl)[ev.ci] = 0;
         wave_sync();
-    } else if (AQ != 0 && __ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+    } else if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+      if constexpr (AQ != 0) {
         // the same comparison as in the LDS form below, the other agents' words coming through quad permutes
         // (lane ^ 1, and with four agents lane ^ 2 and lane ^ 3: all of them other agents of my environment)
         const uint32_t my_pf = (r0.x & 0xFFFFu) | (ev.fxy << 16), my_pos = r0.x & 0xFFFFu;
@@ -962,7 +963,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
             }
         }
 #undef MG_QUAD
-    } else if (__ballot(need_occ || (ev.bits & EV_MAY_WRITE)) != 0) {
+      } else {
         if (mine) pair[lane] = make_uint2((r0.x & 0xFFFFu) | (ev.fxy << 16), ev.bits);
         wave_sync();
         if (mine) {
@@ -1007,6 +1008,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                 }
             }
         }
+      }
     }
     const uint64_t group = (A == 64 ? ~0ull : ((1ull << A) - 1ull)) << (my_slot * A);
     const int kind = p.kind();
@@ -1519,7 +1521,9 @@ template <int V, bool SEE, int MODE, bool WALLED, bool OH, bool MULTI = false, b
 #define MG_WAVES_SINGLE ((SEE && !OH && !COMP && MODE == MODE_STEP) ? 4 : 1)
 #endif
 #ifndef MG_WAVES_MULTI
-#define MG_WAVES_MULTI 3  // the multi-step kernels need 168-182 registers; three wavefronts (168) measured best
+// the multi-step kernels need 146-168 registers: three wavefronts (168) measured best; the cell-table and competitive
+// variants of environments with opaque walls need a few more and would spill at 168, so they get two
+#define MG_WAVES_MULTI (((COMP || CROWD) && !SEE) ? 2 : 3)
 #endif
 __global__ __launch_bounds__(64) MG_KERNEL_ATTR
 __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))) void mg_tile_kernel(const KParams p0) {
