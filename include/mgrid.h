@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 7
+#define MG_ABI_VERSION 8
 
 /* error codes */
 #define MG_OK 0
@@ -51,8 +51,9 @@ extern "C" {
                                          (:573-577), team win at the own door (:484-495), death-match eliminations
                                          (:498-523), pickup rewards and penalty (:425-472); at most 8 agents; agents
                                          act in `order_dev` order = the order of the caller's actions dict (:633-641),
-                                         index order when order_dev is NULL.  Not reproduced: policy objects
-                                         (`policies_map`), the info dicts and the mission texts. */
+                                         index order when order_dev is NULL; the step's info dict comes back through
+                                         MgOut.info_dev.  Not reproduced: policy objects (`policies_map`) and the
+                                         mission texts. */
 
 /* what happens to an environment whose episode ended in this step */
 #define MG_AUTORESET_NONE 0      /* nothing: the caller resets with mg_reset (reference behaviour) */
@@ -112,6 +113,12 @@ typedef struct MgOut {
     double *reward64_dev;    /* [E][A] the step's rewards as the doubles `_reward` computes (base.py:655-659), where
                                 reward_dev holds them rounded to float32; 8-byte aligned; as rows_dev for mg_step_n.
                                 Written by steps only. */
+    uint8_t *info_dev;       /* [E][A] MG_KIND_COMPETITIVE steps only: the info dict of the step per agent
+                                (competative_red_blue_door.py:380-388), packed: bit 0 door_open_done (:490-492), bit 1
+                                got_eliminated_done (:502), bit 2 eliminated_opponents_done and bits 4-7
+                                eliminated_opponent_num (:517-522).  Under "CTCE" the reference keys the dict by team
+                                (:320-328): or the flags and sum the counts over a team's agents.  Not touched for the
+                                other kinds (their info dicts are empty, base.py:408). */
 } MgOut;
 
 typedef struct MgEnv *MgHandle;

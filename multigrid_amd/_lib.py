@@ -19,7 +19,7 @@ MG_OK = 0
 KIND_EMPTY, KIND_REDBLUEDOORS, KIND_BLOCKEDUNLOCKPICKUP, KIND_LOCKEDHALLWAY, KIND_COMPETITIVE = range(5)
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = range(3)
 NUM_STATS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 ONE_HOT_DIM = 24  # 11 types + 6 colours + 7 states, multigrid/wrappers.py:95
 
 EXPORTS = ("mg_abi_version", "mg_create", "mg_destroy", "mg_last_error", "mg_upload_layouts", "mg_generate_layouts",
@@ -39,7 +39,7 @@ class MgConfig(ctypes.Structure):
 class MgOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "image_dev", "direction_dev", "reward_dev", "terminated_dev", "truncated_dev", "onehot_dev",
-        "rows_dev", "reward64_dev")]
+        "rows_dev", "reward64_dev", "info_dev")]
 
 
 class MgLayoutSpec(ctypes.Structure):

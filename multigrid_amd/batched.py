@@ -27,6 +27,7 @@ class StepOutput:
     onehot: Optional[torch.Tensor] = None  # uint8 [E, A, V, V, 24], multigrid/wrappers.py:114-146
     rows: Optional[torch.Tensor] = None      # uint8 [E, A, 8] agent rows of the state the observation shows
     reward64: Optional[torch.Tensor] = None  # float64 [E, A] the rewards as the reference's doubles
+    info: Optional[torch.Tensor] = None      # uint8 [E, A] CompetativeRedBlueDoor: the step's info dict, packed per agent
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -93,7 +94,8 @@ class BatchedMultiGrid:
             batch_envs=int(batch_envs))
         self._h = ctypes.c_void_p()
         check(_lib.lib().mg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
-        if int(spec["kind"]) == _lib.KIND_COMPETITIVE:  # reward_schemes of multigrid/envs/__init__.py:100-108
+        self._competitive = int(spec["kind"]) == _lib.KIND_COMPETITIVE
+        if self._competitive:  # reward_schemes of multigrid/envs/__init__.py:100-108
             rs = np.ascontiguousarray(spec["reward_schemes"], np.float64)
             if rs.shape != (self.A, 4):
                 raise ValueError(f"reward_schemes must be [{self.A}][4], got {rs.shape}")
@@ -105,7 +107,8 @@ class BatchedMultiGrid:
             reward=torch.zeros((e, a), dtype=torch.float32, device=dev),
             terminated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
             truncated=torch.zeros((e, a), dtype=torch.uint8, device=dev),
-            onehot=torch.zeros((e, a, v, v, _lib.ONE_HOT_DIM), dtype=torch.uint8, device=dev) if one_hot else None)
+            onehot=torch.zeros((e, a, v, v, _lib.ONE_HOT_DIM), dtype=torch.uint8, device=dev) if one_hot else None,
+            info=torch.zeros((e, a), dtype=torch.uint8, device=dev) if self._competitive else None)
         self._mgout = self._make_out(self.out)
         self._ea = torch.Size((self.E, self.A))
         self._mg_step = _lib.lib().mg_step
@@ -116,7 +119,7 @@ class BatchedMultiGrid:
     def _make_out(o: StepOutput) -> MgOut:
         p = lambda t: None if t is None else t.data_ptr()
         return MgOut(p(o.image), p(o.direction), p(o.reward), p(o.terminated), p(o.truncated), p(o.onehot),
-                     p(o.rows), p(o.reward64))
+                     p(o.rows), p(o.reward64), p(o.info))
 
     def _stream(self):
         """The current torch stream of this device as a ``hipStream_t``."""
@@ -221,9 +224,10 @@ class BatchedMultiGrid:
                 terminated=torch.empty((t_steps, e, a), dtype=torch.uint8, device=dev),
                 truncated=torch.empty((t_steps, e, a), dtype=torch.uint8, device=dev),
                 onehot=torch.empty((t_steps, e, a, v, v, _lib.ONE_HOT_DIM), dtype=torch.uint8, device=dev)
-                if one_hot else None)
+                if one_hot else None,
+                info=torch.empty((t_steps, e, a), dtype=torch.uint8, device=dev) if self._competitive else None)
         elif any(t is not None and t.shape[0] != t_steps for t in
-                 (out.image, out.direction, out.reward, out.terminated, out.truncated, out.onehot)):
+                 (out.image, out.direction, out.reward, out.terminated, out.truncated, out.onehot, out.info)):
             raise ValueError("out must hold one slice per step")
         mo = self._make_out(out)
         check(_lib.lib().mg_step_n(self._h, t_steps, _ptr(act), _ptr(od), ctypes.byref(mo), self._stream()), self._h)

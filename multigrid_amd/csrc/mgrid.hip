@@ -180,6 +180,7 @@ struct KParams {
     uint8_t *truncated;
     uint8_t *rows_out;   // [E][A][8] agent rows as the launch leaves them in the returned observation's state
     double *reward64;    // [E][A] the rewards as the doubles the reference computes
+    uint8_t *info;       // [E][A] CompetativeRedBlueDoor: the step's info dict, a byte per agent
     LdsMap o;
     MG_EXP(
     int dbg;
@@ -529,6 +530,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
     // "toggle" has neither moved nor turned, so its header entry still names the cell in front of it.
     bool term_all = false;  // a hook terminated every agent
     uint64_t term_some = 0; // a hook terminated these agents (mode "all")
+    uint64_t info_bits = 0; // CompetativeRedBlueDoor: the info dict's bytes, as they are kept in the `tout` bytes
     double paid_sum = 0.0;  // CompetativeRedBlueDoor: sum of this step's rewards
     int comp_cleared = 0;   // ... and the number of cells its hook cleared (`log2`)
     if constexpr (COMP) {
@@ -551,6 +553,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
             racc[k] = byte_of(rewmw, k) ? R : 0.0;  // a goal reached in handle_actions (base.py:491-492)
         }
         uint64_t iterm = termw;  // agent.terminated
+        // the step's info dict (:320-328, :380-388), a byte per agent: bit 0 door_open_done, bit 1 got_eliminated_done,
+        // bit 2 eliminated_opponents_done, bits 4-7 eliminated_opponent_num
+        uint64_t infow = 0;
         if (p.per_agent() && termw != 0 && termw != ones) toutw = 0;  // :375-378: some but not all -> nobody
         uint32_t ball_n = h0.w & 0xFFFF;  // meta[0], meta[1]
         int n2 = 0;
@@ -605,10 +610,14 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                     if (at_door && (w & 15) == T_DOOR && door_open && ((w >> 8) & 127) == my_color) {  // :484-492
 #pragma unroll 1
                         for (int k = 0; k < A; ++k)
-                            if (rows[8 * k + R_COLOR] == my_color && !byte_of(iterm, k)) succeed(k);
+                            if (rows[8 * k + R_COLOR] == my_color && !byte_of(iterm, k)) {
+                                succeed(k);
+                                infow |= 1ull << (8 * k);  // :490-492
+                            }
                     }
                 } else if (p.death_match()) {  // :498-523
                     if (!p.fail_any()) iterm |= 1ull << (8 * victim);  // on_failure without a terminations dict
+                    infow |= 2ull << (8 * victim);  // :502
                     if (at_door && (w & 15) == T_DOOR) flags |= fxy == door_xy[0] ? FLAG_DOOR_GONE : (FLAG_DOOR_GONE << 1);
                     log2[n2++] = ci | (CELL_EMPTY << 16);  // grid.set(*fwd_obj.pos, None), :503
                     const bool blue = rows[8 * victim + R_COLOR] == C_BLUE;  // :504-506
@@ -623,7 +632,10 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                     if (all_gone) {
 #pragma unroll 1
                         for (int k = 0; k < A; ++k)
-                            if (rows[8 * k + R_COLOR] == my_color && !byte_of(iterm, k)) succeed(k);
+                            if (rows[8 * k + R_COLOR] == my_color && !byte_of(iterm, k)) {
+                                succeed(k);
+                                infow = (infow | (4ull << (8 * k))) + (16ull << (8 * k));  // :517-522
+                            }
                     }
                 }
             } else {  // pickup: _default_extra_action_handle_steps, :425-472
@@ -658,6 +670,8 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         h[H_META] = static_cast<uint8_t>(ball_n);
         h[H_META + 1] = static_cast<uint8_t>(ball_n >> 8);
         comp_cleared = n2;
+        // the info bytes travel in the upper bits of the `tout` bytes: terminated | flags << 1 | count << 4
+        info_bits = ((infow & 0x0707070707070707ull) << 1) | (infow & 0xF0F0F0F0F0F0F0F0ull);
     } else if (rbd) {  // redbluedoors.py:176-185
 #pragma unroll 1
         for (int i = 0; i < A; ++i) {
@@ -725,7 +739,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         toutw = ones;  // locked_hallway.py:213-215: only the returned dict
 
     MG_EXP(MG_TICK(q3);)
-    store_bytes(lds + p.o.tout + slot * A, toutw, A);
+    store_bytes(lds + p.o.tout + slot * A, toutw | info_bits, A);
     store_bytes(lds + p.o.rewm + slot * A, rewmw, A);
     const bool all_term = toutw == ones;
     const int paid = static_cast<int>(__builtin_amdgcn_sad_u8(static_cast<uint32_t>(rewmw), 0u,
@@ -2114,6 +2128,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
     float *out_reward = p.reward;
     uint2 *out_rows = nullptr;      // optional outputs of single-step launches (callers that mirror one environment
     double *out_reward64 = nullptr;  // on the host)
+    uint8_t *out_info = COMP ? p.info : nullptr;
     if constexpr (!MULTI) {  // (the multi-step kernel moves its pointers on from step to step)
         out_direction = late_arg<uint8_t *>(offsetof(KParams, direction));
         out_reward = late_arg<float *>(offsetof(KParams, reward));
@@ -2121,6 +2136,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         out_truncated = late_arg<uint8_t *>(offsetof(KParams, truncated));
         out_rows = late_arg<uint2 *>(offsetof(KParams, rows_out));
         out_reward64 = late_arg<double *>(offsetof(KParams, reward64));
+        if (COMP) out_info = late_arg<uint8_t *>(offsetof(KParams, info));
     }
     for (int s = lane; s < nag; s += 64) {
         const int slot = udiv(s, p.magic_a);
@@ -2146,7 +2162,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             const double r = COMP ? R : (m == 0 ? 0.0 : reward_times(R, static_cast<int>(m)));
             if (out_reward) out_reward[o] = static_cast<float>(r);
             if (out_reward64) out_reward64[o] = r;
-            if (out_terminated) out_terminated[o] = static_cast<uint8_t>(tout);
+            if (out_terminated) out_terminated[o] = static_cast<uint8_t>(tout & 1u);
+            if (COMP && out_info) out_info[o] = static_cast<uint8_t>(((tout >> 1) & 7u) | (tout & 0xF0u));
             if (out_truncated) out_truncated[o] = static_cast<uint8_t>(trunc);
         }
     }
@@ -2178,6 +2195,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
         if (p.reward) p.reward += ea;
         if (p.terminated) p.terminated += ea;
         if (p.truncated) p.truncated += ea;
+        if (COMP && p.info) p.info += ea;
     }
     } while (MULTI && ++t < p.T);  // steps of this launch
     if (MODE != MODE_OBS) {
@@ -2799,6 +2817,7 @@ void set_out(KParams &kp, const MgOut *out, int view, int force_stream) {
     kp.truncated = out ? out->truncated_dev : nullptr;
     kp.rows_out = out ? out->rows_dev : nullptr;
     kp.reward64 = out ? out->reward64_dev : nullptr;
+    kp.info = out ? out->info_dev : nullptr;
     // outputs large enough to be streamed past the caches (thresholds measured on MI355X)
     const size_t cells = static_cast<size_t>(kp.E) * kp.A() * view * view;
     kp.bits &= ~(3u << 21);
@@ -3290,6 +3309,7 @@ int mg_step_n(MgHandle h, int32_t num_steps, const uint8_t *actions_dev, const u
             o.truncated_dev = out->truncated_dev ? out->truncated_dev + t * per : nullptr;
             o.rows_dev = out->rows_dev ? out->rows_dev + t * per * 8 : nullptr;
             o.reward64_dev = out->reward64_dev ? out->reward64_dev + t * per : nullptr;
+            o.info_dev = out->info_dev ? out->info_dev + t * per : nullptr;
         }
         const int rc = mg_step(h, actions_dev ? actions_dev + t * per : nullptr, order_dev ? order_dev + t * per : nullptr,
                                out ? &o : nullptr, stream);
@@ -3337,6 +3357,7 @@ int mg_step_shards(const MgHandle *shards, int32_t num_shards, const uint8_t *ac
             o.truncated_dev = out->truncated_dev ? out->truncated_dev + at : nullptr;
             o.rows_dev = out->rows_dev ? out->rows_dev + at * 8 : nullptr;
             o.reward64_dev = out->reward64_dev ? out->reward64_dev + at : nullptr;
+            o.info_dev = out->info_dev ? out->info_dev + at : nullptr;
         }
         const int rc = mg_step(shards[k], actions_dev + at, order_dev ? order_dev + at : nullptr, out ? &o : nullptr,
                                streams ? streams[k] : nullptr);

@@ -88,8 +88,8 @@ class MultiGridEnv:
         a, v = self.num_agents, self.spec["view_size"]
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         n_img = a * v * v * 3
-        self._off = dict(image=0, direction=n_img, terminated=n_img + a, truncated=n_img + 2 * a,
-                         reward=(n_img + 3 * a + 7) // 8 * 8)  # doubles, 8-byte aligned
+        self._off = dict(image=0, direction=n_img, terminated=n_img + a, truncated=n_img + 2 * a, info=n_img + 3 * a,
+                         reward=(n_img + 4 * a + 7) // 8 * 8)  # doubles, 8-byte aligned
         self._off["rows"] = self._off["reward"] + 8 * a  # agent rows of the post-step state, 8 bytes per agent
         total = self._off["rows"] + 8 * a
         self._out_dev = torch.zeros(total, dtype=torch.uint8, device=dev)
@@ -101,7 +101,8 @@ class MultiGridEnv:
                             terminated=blk[o["terminated"]:o["terminated"] + a].view(1, a),
                             truncated=blk[o["truncated"]:o["truncated"] + a].view(1, a),
                             rows=blk[o["rows"]:].view(1, a, 8),
-                            reward64=blk[o["reward"]:o["rows"]].view(torch.float64).view(1, a))
+                            reward64=blk[o["reward"]:o["rows"]].view(torch.float64).view(1, a),
+                            info=blk[o["info"]:o["info"] + a].view(1, a) if self.spec["kind"] == _lib.KIND_COMPETITIVE else None)
         self._in_host = torch.zeros((2, 1, a), dtype=torch.uint8).pin_memory()
         self._in_np = self._in_host.numpy()
         self._in_dev = torch.zeros((2, 1, a), dtype=torch.uint8, device=dev)
@@ -212,6 +213,7 @@ class MultiGridEnv:
                     direction=h[o["direction"]:o["direction"] + a].astype(np.int64),
                     terminated=h[o["terminated"]:o["terminated"] + a].copy(),
                     truncated=h[o["truncated"]:o["truncated"] + a].copy(),
+                    info=h[o["info"]:o["info"] + a].copy(),
                     reward=h[o["reward"]:o["reward"] + 8 * a].view(np.float64).copy())
 
     def _obs_dict(self, got):
@@ -241,8 +243,16 @@ class CompetativeRedBlueDoorEnv(MultiGridEnv):
     agent name (``"red_0"``), actions ``{name: action}`` (:372-423); with "CTCE" by team, actions
     ``{team: [action of each team member]}``, observations ``{team: [{"agent_id", "image", "direction", "mission"}]}``,
     rewards summed and flags and-ed per team (:319-370).  Agents act in the order of the keys of the actions dict
-    (:624-643).  The info dicts and the mission texts the reference rewrites on pickups are not reproduced (infos
-    are empty, the mission stays the first of the mission space's texts)."""
+    (:624-643).  The step's info dict (:320-328, :380-388) is rebuilt from the bytes the launch returns.  The mission
+    texts the reference rewrites on pickups are not reproduced (the mission stays the first of the mission space's
+    texts)."""
+
+    INFO_KEYS = ("door_open_done", "got_eliminated_done", "eliminated_opponents_done", "eliminated_opponent_num")
+
+    @staticmethod
+    def _info_entry(flags: int, count: int) -> dict:
+        return {"door_open_done": bool(flags & 1), "got_eliminated_done": bool(flags & 2),
+                "eliminated_opponents_done": bool(flags & 4), "eliminated_opponent_num": int(count)}
 
     def __init__(self, name: str, device: int | str = 0, layout_rng: Optional[np.random.Generator] = None, **kwargs):
         spec, _ = envs.make_spec(name, **kwargs)
@@ -289,15 +299,19 @@ class CompetativeRedBlueDoorEnv(MultiGridEnv):
         rew = got["reward"]  # doubles, accumulated on the device as the reference accumulates them
         term, trunc = got["terminated"].astype(bool), got["truncated"].astype(bool)
         obs = self._format_obs(self._obs_dict(got))
-        if self.training_scheme == "CTCE":  # :346-368
+        bits = got["info"]  # per agent: flags in bits 0-2, eliminated_opponent_num in bits 4-7
+        if self.training_scheme == "CTCE":  # :346-368; the info entries are the teams' (:320-328)
             rewards = {t: float(sum(rew[k] for k in m)) for t, m in self.team_members.items()}
             terminations = {t: bool(all(term[k] for k in m)) for t, m in self.team_members.items()}
             truncations = {t: bool(all(trunc[k] for k in m)) for t, m in self.team_members.items()}
+            info = {t: self._info_entry(int(np.bitwise_or.reduce(bits[m]) & 7), int((bits[m] >> 4).sum()))
+                    for t, m in self.team_members.items()}
         else:  # :408-421
             rewards = {n: float(rew[k]) for k, n in enumerate(self.agent_names)}
             terminations = {n: bool(term[k]) for k, n in enumerate(self.agent_names)}
             truncations = {n: bool(trunc[k]) for k, n in enumerate(self.agent_names)}
-        return obs, rewards, terminations, truncations, {}
+            info = {n: self._info_entry(int(bits[k]) & 7, int(bits[k]) >> 4) for k, n in enumerate(self.agent_names)}
+        return obs, rewards, terminations, truncations, info
 
 
 class RLlibWrapper:

@@ -44,7 +44,7 @@ def lib():
         p = ctypes.c_void_p
         _lib.mgo_gen_obs.argtypes = [ctypes.POINTER(CSpec), ctypes.c_int64, p, p, p]
         _lib.mgo_gen_obs.restype = None
-        _lib.mgo_step.argtypes = [ctypes.POINTER(CSpec), ctypes.c_int64] + [p] * 12
+        _lib.mgo_step.argtypes = [ctypes.POINTER(CSpec), ctypes.c_int64] + [p] * 13
         _lib.mgo_step.restype = None
     return _lib
 
@@ -76,6 +76,9 @@ class BatchOracle:
         self.reward = np.zeros((e, a), np.float64)
         self.terminated = np.zeros((e, a), np.uint8)
         self.truncated = np.zeros((e, a), np.uint8)
+        # CompetativeRedBlueDoor: the step's info dict per agent, packed (bit 0 door_open_done, bit 1
+        # got_eliminated_done, bit 2 eliminated_opponents_done, bits 4-7 eliminated_opponent_num)
+        self.info = np.zeros((e, a), np.uint8)
 
     def load(self, env_ids, grid, agents, meta):
         """Reset the given environments to the given start states (base.py:310-362)."""
@@ -99,5 +102,5 @@ class BatchOracle:
         lib().mgo_step(ctypes.byref(self.cspec), self.E, _ptr(self.grid), _ptr(self.agents),
                        _ptr(self.meta), _ptr(self.steps), _ptr(self.flags), _ptr(actions),
                        _ptr(order), _ptr(self.image), _ptr(self.direction), _ptr(self.reward),
-                       _ptr(self.terminated), _ptr(self.truncated))
+                       _ptr(self.terminated), _ptr(self.truncated), _ptr(self.info))
         return self.image, self.direction, self.reward, self.terminated, self.truncated

@@ -146,6 +146,8 @@ typedef struct {
     int32_t steps;
     uint8_t flags;
     double *reward;
+    uint8_t *info; /* CompetativeRedBlueDoor: per agent, bit 0 door_open_done, bit 1 got_eliminated_done, bit 2
+                      eliminated_opponents_done, bits 4-7 eliminated_opponent_num (:320-328, :380-388); may be NULL */
 } env_t;
 
 static uint8_t *cell(env_t *e, int x, int y) { return e->grid + ((size_t)x * e->sp->height + y) * 3; }
@@ -247,11 +249,15 @@ static void comp_handle_steps(env_t *e, int i, int act, uint8_t *term_out) {
             if (fx != dx || fy != dy || cell(e, dx, dy)[0] != T_DOOR || (e->flags & (4u << which))) continue;
             if ((comp_door_open(e, 0) || comp_door_open(e, 1)) && cell(e, dx, dy)[1] == ag[ACOLOR])
                 for (int k = 0; k < A; ++k) /* :487-492 */
-                    if (e->agents[8 * k + ACOLOR] == ag[ACOLOR] && !e->agents[8 * k + ATERM]) on_success(e, k, term_out);
+                    if (e->agents[8 * k + ACOLOR] == ag[ACOLOR] && !e->agents[8 * k + ATERM]) {
+                        on_success(e, k, term_out);
+                        if (e->info) e->info[k] |= 1; /* :490-492 */
+                    }
         }
     } else if (sp->death_match) { /* :498-523 */
         uint8_t *v = e->agents + 8 * victim;
         on_failure(e, victim, NULL);
+        if (e->info) e->info[victim] |= 2; /* :502 */
         for (int which = 0; which < 2; ++which) {
             int dx, dy;
             comp_door(e, which, &dx, &dy);
@@ -267,7 +273,10 @@ static void comp_handle_steps(env_t *e, int i, int act, uint8_t *term_out) {
             if (e->agents[8 * k + ACOLOR] != ag[ACOLOR] && !e->agents[8 * k + ATERM]) all_gone = 0;
         if (all_gone)
             for (int k = 0; k < A; ++k)
-                if (e->agents[8 * k + ACOLOR] == ag[ACOLOR] && !e->agents[8 * k + ATERM]) on_success(e, k, term_out);
+                if (e->agents[8 * k + ACOLOR] == ag[ACOLOR] && !e->agents[8 * k + ATERM]) {
+                    on_success(e, k, term_out);
+                    if (e->info) { e->info[k] |= 4; e->info[k] = (uint8_t)(e->info[k] + 16); } /* :517-522 */
+                }
     }
 }
 
@@ -362,10 +371,12 @@ static int popcount6(unsigned m) {
 /* MultiGridEnv.step (base.py:364-408) followed by the subclass hook */
 static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, uint8_t *meta, int32_t *steps,
                      uint8_t *flags, const uint8_t *actions, const uint8_t *order, uint8_t *image,
-                     uint8_t *direction, double *reward, uint8_t *terminated, uint8_t *truncated) {
+                     uint8_t *direction, double *reward, uint8_t *terminated, uint8_t *truncated, uint8_t *info) {
     const int A = sp->num_agents;
-    env_t e = {sp, grid, agents, meta, *steps + 1 /* base.py:395 */, *flags, reward};
+    env_t e = {sp, grid, agents, meta, *steps + 1 /* base.py:395 */, *flags, reward, info};
     for (int k = 0; k < A; ++k) reward[k] = 0; /* base.py:454 */
+    if (info)
+        for (int k = 0; k < A; ++k) info[k] = 0;
     handle_actions(&e, actions, order);
     obs_one(sp, grid, agents, image); /* base.py:399 */
     for (int k = 0; k < A; ++k) {
@@ -426,13 +437,13 @@ static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, uint8_t
 void mgo_step(const mgo_spec *sp, int64_t E, uint8_t *grid, uint8_t *agents, uint8_t *meta,
               int32_t *steps, uint8_t *flags, const uint8_t *actions, const uint8_t *order,
               uint8_t *image, uint8_t *direction, double *reward, uint8_t *terminated,
-              uint8_t *truncated) {
+              uint8_t *truncated, uint8_t *info) {
     const int A = sp->num_agents, V = sp->view_size;
     const size_t gs = (size_t)sp->width * sp->height * 3, as = (size_t)A * 8, is = (size_t)A * V * V * 3;
     for (int64_t e = 0; e < E; ++e)
         step_one(sp, grid + e * gs, agents + e * as, meta + e * 4, steps + e, flags + e,
                  actions + e * A, order ? order + e * A : NULL, image + e * is, direction + e * A,
-                 reward + e * A, terminated + e * A, truncated + e * A);
+                 reward + e * A, terminated + e * A, truncated + e * A, info ? info + e * A : NULL);
 }
 
-int mgo_abi_version(void) { return 2; }
+int mgo_abi_version(void) { return 3; }

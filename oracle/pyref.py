@@ -546,8 +546,10 @@ class Env:
                         for k in range(sp.num_agents):  # :487-492
                             if ag[k, COLOR] == ag[i, COLOR] and not ag[k, TERM]:
                                 self.on_success(k, rewards, terminations)
+                                self.info[k]["door_open_done"] = True
         elif sp.death_match:  # :498-523
             self.on_failure(victim, rewards, None)
+            self.info[victim]["got_eliminated_done"] = True  # :502
             vx, vy = int(ag[victim, X]), int(ag[victim, Y])
             for which, (dx, dy) in enumerate(doors):
                 if (vx, vy) == (dx, dy) and self.grid[dx, dy, 0] == DOOR:
@@ -560,6 +562,8 @@ class Env:
                 for k in range(sp.num_agents):
                     if ag[k, COLOR] == ag[i, COLOR] and not ag[k, TERM]:
                         self.on_success(k, rewards, terminations)
+                        self.info[k]["eliminated_opponents_done"] = True  # :517-522
+                        self.info[k]["eliminated_opponent_num"] += 1
 
     def _comp_pickup_rewards(self, i, act, rewards):
         """_default_extra_action_handle_steps, :425-472 (the handler of agents without a policy object)."""
@@ -598,11 +602,15 @@ class Env:
         truncations = {i: truncated for i in range(sp.num_agents)}
         if sp.per_agent_outputs and any(terminations.values()) and not all(terminations.values()):  # :375-378
             terminations = {i: False for i in terminations}
+        # the info dict of the step, here per agent index (:380-388; ctce_step keys it by team and its entries are
+        # shared by the team's agents, :320-328: or the flags and sum the counts over a team's agents)
+        self.info = {i: {"door_open_done": False, "got_eliminated_done": False, "eliminated_opponents_done": False,
+                         "eliminated_opponent_num": 0} for i in range(sp.num_agents)}
         for i in order:
             i = int(i)
             self._comp_handle_steps(i, int(actions[i]), rewards, terminations)
             self._comp_pickup_rewards(i, int(actions[i]), rewards)
-        return obs, rewards, terminations, truncations, {}
+        return obs, rewards, terminations, truncations, self.info
 
     def is_done(self) -> bool:
         """base.py:587-596."""

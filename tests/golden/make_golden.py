@@ -465,6 +465,9 @@ def comp_hidden(env, keys, balls):
     return flags, meta
 
 
+INFO_KEYS = ("door_open_done", "got_eliminated_done", "eliminated_opponents_done", "eliminated_opponent_num")
+
+
 def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None, script=None, extra_after_done=3,
                        view=None, ctce=False):
     """Trajectories of CompetativeRedBlueDoorEnvV3 with its default step handlers (policies_map = {}).  The order in
@@ -521,7 +524,7 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
             layout_meta=np.zeros(4, np.uint8),
             reset_image=np.stack([o["image"] for o in obs]).astype(np.uint8),
             actions=[], order=[], image=[], direction=[], reward=[], terminated=[], truncated=[], post_grid=[],
-            post_agents=[], post_flags=[], post_meta=[])
+            post_agents=[], post_flags=[], post_meta=[], info=[])
         after = 0
         for t in range(t_max):
             if script is not None and t < len(script(n)):
@@ -533,11 +536,11 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
             if ctce:  # one list of actions per team; teams, and so their agents, act in the order of the dict
                 team_order = [teams[j] for j in rng.permutation(len(teams))]
                 order = np.array([k for tm in team_order for k in members[tm]])
-                o, r, term, trunc, _ = env.step({tm: [int(acts[k]) for k in members[tm]] for tm in team_order})
+                o, r, term, trunc, inf = env.step({tm: [int(acts[k]) for k in members[tm]] for tm in team_order})
                 out_keys = teams   # rewards summed, flags and-ed per team (:346-368)
             else:
                 order = rng.permutation(a)
-                o, r, term, trunc, _ = env.step({names[i]: int(acts[i]) for i in order})
+                o, r, term, trunc, inf = env.step({names[i]: int(acts[i]) for i in order})
                 out_keys = names
             o = per_agent(o)
             tr["actions"].append(acts.astype(np.uint8))
@@ -549,6 +552,9 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
             tr["reward"].append(np.array([float(r[nm]) for nm in out_keys], np.float64))
             tr["terminated"].append(np.array([bool(term[nm]) for nm in out_keys]))
             tr["truncated"].append(np.array([bool(trunc[nm]) for nm in out_keys]))
+            # the info dict of the step (:320-328, :380-388): per agent name, or per team under CTCE
+            assert set(inf) == set(out_keys) and all(set(inf[nm]) == set(INFO_KEYS) for nm in out_keys)
+            tr["info"].append(np.array([[int(inf[nm][k]) for k in INFO_KEYS] for nm in out_keys], np.uint8))
             tr["post_grid"].append(env.grid.state.astype(np.uint8).copy())
             tr["post_agents"].append(agent_rows(env))
             fl, mt = comp_hidden(env, keys, balls)
@@ -566,7 +572,7 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
     for key in ("layout_grid", "layout_agents", "layout_meta", "reset_image"):
         out[key] = np.stack([t[key] for t in trajs])
     for key in ("actions", "order", "image", "direction", "reward", "terminated", "truncated", "post_grid",
-                "post_agents", "post_flags", "post_meta"):
+                "post_agents", "post_flags", "post_meta", "info"):
         first = np.asarray(trajs[0][key][0])
         arr = np.zeros((n, tm) + first.shape, dtype=first.dtype)
         for i, t in enumerate(trajs):
@@ -574,6 +580,7 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
         out[key] = arr
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
+    print(f"info events {out['info'].reshape(-1, 4).sum(axis=0).tolist()}", end="  ")
     print(f"{name:28s} traj={n:3d} steps={int(lens.sum()):6d} nonzero_rewards={int((out['reward'] != 0).sum()):5d} "
           f"positive={int((out['reward'] > 0).sum()):4d} below_minus_half={int((out['reward'] < -0.5).sum()):3d} "
           f"traj_with_termination={int(out['terminated'].any(axis=(1, 2)).sum()):3d} "

@@ -34,3 +34,33 @@ def load_group(name):
 def load_layout_fixture():
     with np.load(os.path.join(GOLDEN_DIR, "layouts.npz")) as z:
         return {k: z[k] for k in z.files}
+
+
+INFO_KEYS = ("door_open_done", "got_eliminated_done", "eliminated_opponents_done", "eliminated_opponent_num")
+
+
+def pack_info(rows):
+    """The recorded info entries ``[..., 4]`` (the reference's info dict of a CompetativeRedBlueDoor step, in the order of
+    INFO_KEYS) as the bytes the library and the C oracle return: bit 0 door_open_done, bit 1 got_eliminated_done,
+    bit 2 eliminated_opponents_done, bits 4-7 eliminated_opponent_num."""
+    rows = np.asarray(rows).astype(np.uint8)
+    return ((rows[..., 0] != 0) | ((rows[..., 1] != 0) << 1) | ((rows[..., 2] != 0) << 2) | (rows[..., 3] << 4)).astype(np.uint8)
+
+
+def pack_info_dict(info, keys):
+    """The same bytes from an info dict ``{key: {name: value}}`` for the given keys, in order."""
+    return pack_info([[int(info[k][name]) for name in INFO_KEYS] for k in keys])
+
+
+def team_info(members, packed):
+    """Per-agent info bytes -> per-team bytes as ctce_step reports them (its entries are shared by the team's agents,
+    multigrid/envs/competative_red_blue_door.py:320-328): flags or-ed, counts summed over each team's agents."""
+    out = []
+    for team in members:
+        flags = 0
+        count = 0
+        for k in team:
+            flags |= int(packed[k]) & 7
+            count += int(packed[k]) >> 4
+        out.append(flags | (count << 4))
+    return np.asarray(out, np.uint8)

@@ -69,6 +69,12 @@ def compare(out, ora_out, where, image=True):
     np.testing.assert_array_equal(out.truncated.cpu().numpy(), trunc, err_msg=where + " truncated")
 
 
+def compare_info(out, info, where):
+    """CompetativeRedBlueDoor: the step's info dict as a byte per agent (bit 0 door_open_done, bit 1 got_eliminated_done,
+    bit 2 eliminated_opponents_done, bits 4-7 eliminated_opponent_num)."""
+    np.testing.assert_array_equal(out.info.cpu().numpy(), info, err_msg=where + " info")
+
+
 def compare_state(env, ora, where):
     st = env.get_state()
     np.testing.assert_array_equal(st["grid"].cpu().numpy(), ora.grid, err_msg=where + " grid")

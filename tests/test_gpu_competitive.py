@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from multigrid_amd import envs, layouts
-from test_gpu_batch import compare, compare_state, expected_layout
+from test_gpu_batch import compare, compare_info, compare_state, expected_layout
 
 pytestmark = pytest.mark.gpu
 
@@ -78,7 +78,7 @@ def test_competitive_against_oracle(name, kw, mode):
     np.testing.assert_array_equal(out.image.cpu().numpy(), ora.gen_obs())
     crowd(ora, rng)
     env.set_state(grid=ora.grid, agents=ora.agents)
-    seen = dict(win=0, kill=0, fl=set())
+    seen = dict(win=0, kill=0, fl=set(), info=set())
     for t in range(60):
         actions = rng.choice(7, size=(e, a), p=PICKY).astype(np.uint8)
         order = np.argsort(rng.random((e, a)), axis=1).astype(np.uint8)
@@ -86,6 +86,8 @@ def test_competitive_against_oracle(name, kw, mode):
         out = env.step(actions, order if give_order else None)   # without an order: index order
         img, direction, rew, term, trunc = ora.step(actions, order if give_order else None)
         img, direction = img.copy(), direction.copy()
+        compare_info(out, ora.info, f"{name} mode {mode} step {t}")
+        seen["info"].update(np.unique(ora.info).tolist())
         seen["win"] += int((rew > 0.6).sum())
         seen["kill"] += int((rew < -0.5).sum())
         seen["fl"].update(np.unique(ora.flags).tolist())
@@ -110,9 +112,10 @@ def test_competitive_against_oracle(name, kw, mode):
         if t % 10 == 9:
             compare_state(env, ora, f"{name} mode {mode} step {t}")
     compare_state(env, ora, f"{name} final")
-    assert seen["win"] > 0
+    assert seen["win"] > 0 and 1 in seen["info"]  # door_open_done
     if spec["death_match"] and a > 1 and len(set(ora.agents[0, :, 7])) > 1:
-        assert seen["kill"] > 0
+        assert seen["kill"] > 0 and 2 in seen["info"]  # got_eliminated_done
+        assert any(v >> 4 for v in seen["info"])  # eliminated_opponent_num
     env.close()
 
 
@@ -139,6 +142,7 @@ def test_competitive_multi_step_launch(name, kw, mode):
         for t in range(t_steps):
             img, direction, rew, term, trunc = ora.step(acts[t], order[t])
             img, direction = img.copy(), direction.copy()
+            np.testing.assert_array_equal(out.info[t].cpu().numpy(), ora.info, err_msg=f"{name} call {call} slice {t} info")
             done = term.all(axis=1) | trunc.all(axis=1)
             if mode != 0 and done.any():
                 ids = np.nonzero(done)[0]

@@ -3,7 +3,7 @@ layouts come from the host generators, agent orders from np_random, exactly as i
 import numpy as np
 import pytest
 
-from golden_util import load_group
+from golden_util import INFO_KEYS, load_group, pack_info, pack_info_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -84,6 +84,8 @@ def test_competitive_env_from_seed_dtde():
             np.testing.assert_allclose([r[k] for k in names], d["reward"][n, t], atol=1e-6, rtol=0, err_msg=where)
             assert [term[k] for k in names] == list(d["terminated"][n, t]), where
             assert [trunc[k] for k in names] == list(d["truncated"][n, t]), where
+            assert list(info) == names and list(info[names[0]]) == list(INFO_KEYS), where
+            np.testing.assert_array_equal(pack_info_dict(info, names), pack_info(d["info"][n, t]), err_msg=where + " info")
         env.close()
 
 
@@ -110,8 +112,9 @@ def test_competitive_env_ctce_team_outputs():
                 if tm not in team_order:
                     team_order.append(tm)
             acts = {tm: [int(d["actions"][n, t, k]) for k in env.team_members[tm]] for tm in team_order}
-            o, r, term, trunc, _ = env.step(acts)
+            o, r, term, trunc, info = env.step(acts)
             where = f"ctce_2v2[{n}] step {t}"
+            np.testing.assert_array_equal(pack_info_dict(info, teams), pack_info(d["info"][n, t]), err_msg=where + " info")
             img = np.zeros_like(d["image"][n, t])
             for tm in teams:
                 for j, k in enumerate(env.team_members[tm]):

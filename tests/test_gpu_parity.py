@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from golden_util import group_names, load_group
+from golden_util import group_names, load_group, pack_info
 
 pytestmark = pytest.mark.gpu
 
@@ -44,4 +44,6 @@ def test_hip_replays_reference(name):
         if "post_flags" in d:  # CompetativeRedBlueDoorEnvV3: key objects used up, doors orphaned, ball discounts
             np.testing.assert_array_equal(st["flags"].cpu().numpy()[live], d["post_flags"][live, t], err_msg=where + " flags")
             np.testing.assert_array_equal(st["meta"].cpu().numpy()[live], d["post_meta"][live, t], err_msg=where + " meta")
+        if "info" in d:  # the step's info dict (multigrid/envs/competative_red_blue_door.py:380-388), a byte per agent
+            np.testing.assert_array_equal(out.info.cpu().numpy()[live], pack_info(d["info"][live, t]), err_msg=where + " info")
     env.close()

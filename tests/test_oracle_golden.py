@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from golden_util import group_names, load_group
+from golden_util import group_names, load_group, pack_info, pack_info_dict, team_info
 from oracle import pyref
 
 
@@ -22,8 +22,10 @@ def test_pyref_replays_reference(name, fast_obs):
         np.testing.assert_array_equal(img0, d["reset_image"][n], err_msg=f"{name}[{n}] reset obs")
         for t in range(int(d["length"][n])):
             acts = d["actions"][n, t]
-            o, r, term, trunc, _ = env.step({i: int(acts[i]) for i in range(a)}, d["order"][n, t])
+            o, r, term, trunc, info = env.step({i: int(acts[i]) for i in range(a)}, d["order"][n, t])
             where = f"{name}[{n}] step {t}"
+            if "info" in d:  # CompetativeRedBlueDoorEnvV3: the step's info dict
+                np.testing.assert_array_equal(pack_info_dict(info, range(a)), pack_info(d["info"][n, t]), err_msg=where + " info")
             img = np.stack([o[i]["image"] for i in range(a)])
             np.testing.assert_array_equal(img, d["image"][n, t], err_msg=where + " image")
             np.testing.assert_array_equal([int(o[i]["direction"]) for i in range(a)],
@@ -65,6 +67,7 @@ def test_c_oracle_replays_reference(name):
         if "post_flags" in d:
             np.testing.assert_array_equal(bo.flags[live], d["post_flags"][live, t], err_msg=where + " flags")
             np.testing.assert_array_equal(bo.meta[live], d["post_meta"][live, t], err_msg=where + " ball counters")
+            np.testing.assert_array_equal(bo.info[live], pack_info(d["info"][live, t]), err_msg=where + " info")
 
 
 def team_outputs(members, reward, terminated, truncated):
@@ -101,7 +104,10 @@ def test_ctce_outputs():
             if d["length"][k] <= t:
                 continue
             where = f"ctce_2v2[{k}] step {t}"
-            o, r, tm, tr, _ = envs_py[k].step({i: int(d["actions"][k, t, i]) for i in range(a)}, d["order"][k, t])
+            o, r, tm, tr, info = envs_py[k].step({i: int(d["actions"][k, t, i]) for i in range(a)}, d["order"][k, t])
+            want_info = pack_info(d["info"][k, t])
+            np.testing.assert_array_equal(team_info(members, pack_info_dict(info, range(a))), want_info, err_msg=where + " info")
+            np.testing.assert_array_equal(team_info(members, bo.info[k]), want_info, err_msg=where + " info (C)")
             for got in (team_outputs(members, r, tm, tr), team_outputs(members, rew[k], term[k], trunc[k])):
                 assert got[0] == list(d["reward"][k, t]), where + " team rewards"
                 assert got[1] == list(d["terminated"][k, t]), where + " team terminations"
