@@ -15,6 +15,13 @@ This is the contract of ``gymnasium.vector.SyncVectorEnv`` as the reference uses
   tensors every step (zeros where no episode ended) and leaves out the per-environment Python objects.
   Those three tensors are written in place, two sets used in turn: what one ``step`` returned is overwritten by
   the second ``step`` after it (observations, rewards and flags already by the next one), so copy what must last.
+* ``final_observation=True`` adds the other half of that contract, ``infos["final_observation"]``: the observation
+  of the state the finished episode ended in, which the returned observation (the next episode's first) has
+  replaced.  The step is then taken without the restart inside the launch; the terminal observations are copied
+  aside and one masked ``mg_reset`` launch restarts the finished environments (same start states, same order
+  stream, same results as the one-launch form; two more launches and one copy of the observations per step).
+  With ``numpy=True`` it is an object array of per-environment observations (``None`` elsewhere) next to
+  ``infos["_final_observation"]``; otherwise the whole batch's tensors, meaningful where ``infos["_final_info"]`` is set.
 
 Every array is a PyTorch-ROCm tensor written in place by the HIP kernels (``numpy=True`` converts
 at the boundary like ``SyncVectorEnv`` does).  With ``single_agent=True`` (one agent per
@@ -36,7 +43,8 @@ from .batched import BatchedMultiGrid
 class MultiGridVectorEnv:
     def __init__(self, name: str, num_envs: int, agents: Optional[int] = None, device: int | str = 0,
                  num_layouts: int = 1024, seed: int = 0, one_hot: bool = False, single_agent: bool = False,
-                 numpy: bool = False, env_id_offset: int = 0, device_layouts: bool = False, **kwargs):
+                 numpy: bool = False, env_id_offset: int = 0, device_layouts: bool = False,
+                 final_observation: bool = False, **kwargs):
         """``device_layouts``: draw the pool of start states on the GPU (``mg_generate_layouts``) instead of
         generating it on the host; large pools then cost milliseconds."""
         self.spec, self._gen = envs.make_spec(name, num_agents=agents, **kwargs)
@@ -46,8 +54,10 @@ class MultiGridVectorEnv:
             raise ValueError("single_agent=True needs agents=1")
         self.single_agent, self.one_hot, self.numpy = single_agent, one_hot, numpy
         self.num_actions = 7  # multigrid/core/actions.py:4-15
-        self._sim = BatchedMultiGrid(self.spec, self.num_envs, device=device, autoreset=_lib.AUTORESET_SAME_STEP,
-                                     env_id_offset=env_id_offset, seed=seed, one_hot=one_hot)
+        self.final_observation = bool(final_observation)
+        self._sim = BatchedMultiGrid(self.spec, self.num_envs, device=device, env_id_offset=env_id_offset, seed=seed,
+                                     one_hot=one_hot, autoreset=_lib.AUTORESET_NONE
+                                     if self.final_observation else _lib.AUTORESET_SAME_STEP)
         self._num_layouts, self._seed, self._device_layouts = int(num_layouts), int(seed), bool(device_layouts)
         self._uploaded = None
         dev = self._sim.device
@@ -58,6 +68,10 @@ class MultiGridVectorEnv:
         self._ep_len = torch.zeros((2, self.num_envs), dtype=torch.int64, device=dev)
         self._done = torch.zeros((2, self.num_envs), dtype=torch.uint8, device=dev)
         self._flip = 0
+        if self.final_observation:
+            o = self._sim.out
+            self._final_image = torch.zeros_like(o.onehot if one_hot else o.image)
+            self._final_dir = torch.zeros_like(o.direction)
         self._mg_episode_stats = _lib.lib().mg_episode_stats
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         o = self._sim.out  # every tensor involved lives as long as this object: the argument lists are made once
@@ -110,11 +124,19 @@ class MultiGridVectorEnv:
         if rc != 0:
             _lib.check(rc)
         infos = {}
+        if self.final_observation:
+            # the terminal observations aside, then the finished environments restarted by one masked reset launch
+            # that writes their first observations over them
+            self._final_image.copy_(out.onehot if self.one_hot else out.image)
+            self._final_dir.copy_(out.direction)
+            self._sim.reset(mask=self._done[self._flip ^ 1])
         if not self.numpy:
             # everything stays on the GPU and nothing here waits for it
             infos["_final_info"] = done
             infos["episode_return"] = self._view(ep_ret)
             infos["episode_length"] = ep_len
+            if self.final_observation:
+                infos["final_observation"] = {"image": self._view(self._final_image), "direction": self._view(self._final_dir)}
         elif bool(done.any()):
             infos["_final_info"] = self._view_mask(done)
             infos["episode_return"] = self._view(ep_ret)
@@ -125,6 +147,13 @@ class MultiGridVectorEnv:
             for k, i in enumerate(idx):
                 final[i] = {"episode": {"r": float(r[k, 0]) if self.single_agent else r[k], "l": int(l[k])}}
             infos["final_info"] = final
+            if self.final_observation:
+                img, direction = self._view(self._final_image), self._view(self._final_dir)
+                last = np.full((self.num_envs,), None, dtype=object)
+                for i in idx:
+                    last[i] = {"image": img[i], "direction": direction[i]}
+                infos["final_observation"] = last
+                infos["_final_observation"] = infos["_final_info"]
         # (the flags are bytes of 0 / 1: reinterpreted as booleans, not converted)
         return (self._obs(out), self._view(out.reward), self._view(out.terminated.view(torch.bool)),
                 self._view(out.truncated.view(torch.bool)), infos)

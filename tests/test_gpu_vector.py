@@ -19,7 +19,8 @@ def device_order_for(seed, gid, episode, step, a):
     ("MultiGrid-LockedHallway-2Rooms-v0", 3, False, dict(max_steps=35)),
     ("MultiGrid-Empty-6x6-v0", 2, False, dict(max_steps=24)),
 ])
-def test_vector_env_contract(name, agents, single, kw):
+@pytest.mark.parametrize("final_obs", [False, True])
+def test_vector_env_contract(name, agents, single, kw, final_obs):
     import torch
     from multigrid_amd.vector import MultiGridVectorEnv
     from oracle.coracle import BatchOracle
@@ -27,7 +28,8 @@ def test_vector_env_contract(name, agents, single, kw):
 
     n, n_layouts, seed = 700, 48, 21
     venv = MultiGridVectorEnv(name, n, agents=agents, device=0, num_layouts=n_layouts, seed=seed,
-                              single_agent=single, numpy=True, one_hot=True, agent_view_size=7, **kw)
+                              single_agent=single, numpy=True, one_hot=True, agent_view_size=7,
+                              final_observation=final_obs, **kw)
     spec, gen = envs.make_spec(name, num_agents=agents, **dict(dict(agent_view_size=7), **kw))
     pool = layouts.make_pool(gen, n_layouts, seed0=seed)
     ora = BatchOracle(spec, n)
@@ -65,6 +67,17 @@ def test_vector_env_contract(name, agents, single, kw):
                     assert infos["final_info"][i] is None
             np.testing.assert_allclose(infos["episode_return"], squeeze(np.where(done[:, None], ret, 0.0)), atol=1e-5)
             np.testing.assert_array_equal(infos["episode_length"], np.where(done, length, 0))
+            if final_obs:  # the observation the finished episode ended on (SyncVectorEnv's info["final_observation"])
+                assert np.array_equal(infos["_final_observation"], done)
+                last = squeeze(pyref.one_hot_batch(img))
+                for i in range(n):
+                    if done[i]:
+                        np.testing.assert_array_equal(infos["final_observation"][i]["image"], last[i])
+                        np.testing.assert_array_equal(infos["final_observation"][i]["direction"], squeeze(direction)[i])
+                    else:
+                        assert infos["final_observation"][i] is None
+            else:
+                assert "final_observation" not in infos
             ret[ids] = 0
             length[ids] = 0
             episode[ids] += 1
