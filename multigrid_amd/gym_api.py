@@ -13,6 +13,7 @@ multigrid/rllib/__init__.py:47-76 and multigrid/pettingzoo/__init__.py:35-70 by 
 """
 from __future__ import annotations
 
+import ctypes
 from collections import defaultdict
 from typing import Any, Dict, Optional
 
@@ -68,6 +69,18 @@ def _spaces():
         return BoxSpec, DiscreteSpec, dict
 
 
+def _gpu_addresses(pinned: torch.Tensor) -> bool:
+    """Whether the current GPU addresses this pinned host tensor at its host address (hipHostGetDevicePointer), so that
+    kernels can be handed ``data_ptr()`` as it is."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        dev_ptr = ctypes.c_void_p()
+        rc = hip.hipHostGetDevicePointer(ctypes.byref(dev_ptr), ctypes.c_void_p(pinned.data_ptr()), ctypes.c_uint(0))
+        return rc == 0 and dev_ptr.value == pinned.data_ptr()
+    except (OSError, AttributeError):
+        return False
+
+
 class MultiGridEnv:
     metadata = {"render_modes": [], "render_fps": 20}
 
@@ -81,10 +94,12 @@ class MultiGridEnv:
         self.num_agents = self.spec["num_agents"]
         self.max_steps = self.spec["max_steps"]
         self.width, self.height = self.spec["width"], self.spec["height"]
-        # Everything a step returns lives in ONE device block (the launch's outputs are views into it, the agent rows
-        # of the state it leaves and the rewards as doubles among them) that comes back with one copy into pinned host
-        # memory; actions and agent order go up as one pinned block too: a step is one upload, one launch, one
-        # download and one wait.
+        # Everything a step returns lives in ONE block (the launch's outputs are views into it, the agent rows of the
+        # state it leaves and the rewards as doubles among them), actions and agent order in another.  Both blocks are
+        # pinned host memory that the GPU addresses directly: the kernel reads its 2 A input bytes from it and writes
+        # its few hundred output bytes to it over the bus, so a step is one launch and one wait, with no copy
+        # operations queued around it.  (Where the runtime does not map pinned memory at its host address, the blocks
+        # are device memory and travel by one upload and one download per step.)
         a, v = self.num_agents, self.spec["view_size"]
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         n_img = a * v * v * 3
@@ -92,9 +107,14 @@ class MultiGridEnv:
                          reward=(n_img + 4 * a + 7) // 8 * 8)  # doubles, 8-byte aligned
         self._off["rows"] = self._off["reward"] + 8 * a  # agent rows of the post-step state, 8 bytes per agent
         total = self._off["rows"] + 8 * a
-        self._out_dev = torch.zeros(total, dtype=torch.uint8, device=dev)
-        self._out_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        with torch.cuda.device(dev):
+            self._out_host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+            self._in_host = torch.zeros((2, 1, a), dtype=torch.uint8).pin_memory()
+            self._zero_copy = _gpu_addresses(self._out_host) and _gpu_addresses(self._in_host)
         self._out_np = self._out_host.numpy()
+        self._in_np = self._in_host.numpy()
+        self._out_dev = self._out_host if self._zero_copy else torch.zeros(total, dtype=torch.uint8, device=dev)
+        self._in_dev = self._in_host if self._zero_copy else torch.zeros((2, 1, a), dtype=torch.uint8, device=dev)
         o, blk = self._off, self._out_dev
         packed = StepOutput(image=blk[:n_img].view(1, a, v, v, 3), direction=blk[o["direction"]:o["direction"] + a].view(1, a),
                             reward=None,
@@ -103,10 +123,9 @@ class MultiGridEnv:
                             rows=blk[o["rows"]:].view(1, a, 8),
                             reward64=blk[o["reward"]:o["rows"]].view(torch.float64).view(1, a),
                             info=blk[o["info"]:o["info"] + a].view(1, a) if self.spec["kind"] == _lib.KIND_COMPETITIVE else None)
-        self._in_host = torch.zeros((2, 1, a), dtype=torch.uint8).pin_memory()
-        self._in_np = self._in_host.numpy()
-        self._in_dev = torch.zeros((2, 1, a), dtype=torch.uint8, device=dev)
         self._sim = BatchedMultiGrid(self.spec, 1, device=dev, autoreset=_lib.AUTORESET_NONE, out=packed)
+        self._act_ptr = ctypes.c_void_p(self._in_dev[0].data_ptr())
+        self._order_ptr = ctypes.c_void_p(self._in_dev[1].data_ptr())
         self._layout0 = torch.zeros(1, dtype=torch.int32, device=dev)
         # RandomMixin keeps the generator that existed at construction time (multigrid/base.py:153);
         # gym.Env.np_random is the same object until reset(seed) replaces it.
@@ -196,17 +215,21 @@ class MultiGridEnv:
         """One upload (actions and order), the step launch, one download of everything it returned."""
         self._in_np[0, 0, :] = acts
         self._in_np[1, 0, :] = order
-        self._in_dev.copy_(self._in_host, non_blocking=True)
-        self._sim.step(self._in_dev[0], self._in_dev[1])
+        sim = self._sim
+        if not self._zero_copy:
+            self._in_dev.copy_(self._in_host, non_blocking=True)
+        rc = sim._mg_step(sim._h, self._act_ptr, self._order_ptr, ctypes.byref(sim._mgout), sim._stream())
+        if rc != 0:
+            _lib.check(rc, sim._h)
         self.step_count += 1
         return self._fetch()
 
     def _fetch(self):
         """The packed output block of the last launch as host arrays (copies: the pinned block is reused)."""
-        stream = torch.cuda.current_stream(self._out_dev.device)
         # (the agent rows of the state the launch left behind - is_done, agent_states - travel in the same block)
-        self._out_host.copy_(self._out_dev, non_blocking=True)
-        stream.synchronize()
+        if not self._zero_copy:
+            self._out_host.copy_(self._out_dev, non_blocking=True)
+        torch.cuda.current_stream(self._sim.device).synchronize()
         a, v, o, h = self.num_agents, self.spec["view_size"], self._off, self._out_np
         self._rows = h[o["rows"]:o["rows"] + 8 * a].reshape(a, 8).copy()
         return dict(image=h[:o["direction"]].reshape(a, v, v, 3).astype(np.int64),

@@ -19,9 +19,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("pinned_blocks", [True, False])
 @pytest.mark.parametrize("group,name,agents,seed0,kw", CASES)
-def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw):
+def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw, pinned_blocks, monkeypatch):
+    """``pinned_blocks``: the kernel reads actions from and writes its outputs to pinned host memory (one launch and one
+    wait per step); otherwise the blocks are device memory and travel by one upload and one download."""
+    from multigrid_amd import gym_api
     from multigrid_amd.gym_api import MultiGridEnv, PettingZooWrapper, RLlibWrapper
+    if not pinned_blocks:
+        monkeypatch.setattr(gym_api, "_gpu_addresses", lambda t: False)
 
     spec, d = load_group(group)
     kw = dict(kw)
@@ -32,6 +38,7 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw)
     view = spec["view_size"]
     for n in range(min(3, len(d["length"]))):
         env = MultiGridEnv(name, agents=agents, layout_rng=np.random.default_rng(seed0 * 1000 + n), **kw)
+        assert env._zero_copy == pinned_blocks  # (this GPU maps pinned memory at its host address)
         obs, infos = env.reset(seed=seed0 * 7919 + n)
         assert set(obs) == set(range(agents)) and obs[0]["image"].dtype == np.int64
         np.testing.assert_array_equal(np.stack([obs[i]["image"] for i in range(agents)]), d["reset_image"][n])
