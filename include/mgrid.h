@@ -67,8 +67,10 @@ typedef struct MgConfig {
     int32_t kind;                /* MG_KIND_* */
     int32_t width, height;       /* grid size W, H                      base.py:162-165 */
     int32_t num_agents;          /* A                                    base.py:172-178 */
-    int32_t view_size;           /* V: 3, 5 or 7 only (the reference takes any odd size; its default is 5,
-                                    its registry entries never set it); MG_EINVAL otherwise   base.py:96 */
+    int32_t view_size;           /* V: 3, 5, 7, 9 or 11 (the reference takes any odd size; its default is 5, its
+                                    registry entries never set it); MG_EINVAL otherwise.  9 and 11 run the
+                                    general forms of the step kernel only (mg_step_n then queues single
+                                    steps)                                                   base.py:96 */
     int32_t max_steps;           /*                                      base.py:94 */
     int32_t see_through_walls;   /*                                      base.py:95 */
     int32_t allow_agent_overlap; /*                                      base.py:97 */

@@ -1532,7 +1532,7 @@ template <int V, bool SEE, int MODE, bool WALLED, bool OH, bool MULTI = false, b
 // there without a spill when an unrelated change nudges the allocator.  The others need 139-170 registers and lose
 // more to spills than a fourth wavefront gives (measured), so they are left alone.  Tuning builds can override.
 #ifndef MG_WAVES_SINGLE
-#define MG_WAVES_SINGLE ((SEE && !OH && !COMP && MODE == MODE_STEP) ? 4 : 1)
+#define MG_WAVES_SINGLE ((SEE && !OH && !COMP && MODE == MODE_STEP && V <= 7) ? 4 : 1)
 #endif
 #ifndef MG_WAVES_MULTI
 // the multi-step kernels need 146-168 registers: three wavefronts (168) measured best; the cell-table and competitive
@@ -2770,12 +2770,40 @@ void launch_vm(const MgEnv *h, const KParams &kp, hipStream_t s) {
     if (h->cfg.see_through_walls) launch_vs<V, true, MODE>(h, kp, s); else launch_vs<V, false, MODE>(h, kp, s);
 }
 
+// View sizes 9 and 11 (the reference takes any odd agent_view_size, multigrid/base.py:96; none of its registered
+// configurations sets one above 7): the same kernel with 61 / 91 registers of image per lane, in its general forms
+// only - general border code, default staging width, lane-per-agent act phase without the cell table, one step per
+// launch (mg_step_n queues single steps).
+template <int V, int MODE>
+void launch_big(const MgEnv *h, const KParams &kp_in, hipStream_t s) {
+    KParams kp = kp_in;
+    constexpr int STG0 = MG_STAGE_LANES;
+    kp.o.oh = static_cast<lds_off_t>(h->lds_bytes);
+    const bool see = h->cfg.see_through_walls != 0;
+    if (kp.onehot) {
+        if (see) launch_k<V, true, MODE, false, true, false, false, false, STG0>(h, kp, h->lds_bytes + OH_XCHG_BYTES, s);
+        else launch_k<V, false, MODE, false, true, false, false, false, STG0>(h, kp, h->lds_bytes + OH_XCHG_BYTES, s);
+        return;
+    }
+    if constexpr (MODE == MODE_STEP) {
+        if (kp.comp()) {
+            if (see) launch_k<V, true, MODE, false, false, false, true, false, STG0>(h, kp, h->lds_bytes, s);
+            else launch_k<V, false, MODE, false, false, false, true, false, STG0>(h, kp, h->lds_bytes, s);
+            return;
+        }
+    }
+    if (see) launch_k<V, true, MODE, false, false, false, false, false, STG0>(h, kp, h->lds_bytes, s);
+    else launch_k<V, false, MODE, false, false, false, false, false, STG0>(h, kp, h->lds_bytes, s);
+}
+
 template <int MODE>
 int launch_tile(MgEnv *h, const KParams &kp, hipStream_t s) {
     switch (h->cfg.view_size) {
 #ifndef MG_ONLY_VIEW7  // tuning builds compile the 7 x 7 kernels alone
         case 3: launch_vm<3, MODE>(h, kp, s); break;
         case 5: launch_vm<5, MODE>(h, kp, s); break;
+        case 9: launch_big<9, MODE>(h, kp, s); break;
+        case 11: launch_big<11, MODE>(h, kp, s); break;
 #endif
         case 7: launch_vm<7, MODE>(h, kp, s); break;
         default: return fail(h, MG_EINVAL, "view_size %d not supported", h->cfg.view_size);
@@ -2854,8 +2882,8 @@ int configure(MgEnv *h, const MgConfig &c) {
                     c.height);
     if (c.num_agents < 1 || c.num_agents > 64)
         return fail(nullptr, MG_EINVAL, "num_agents %d not supported (1..64)", c.num_agents);
-    if (c.view_size != 3 && c.view_size != 5 && c.view_size != 7)
-        return fail(nullptr, MG_EINVAL, "view_size %d not supported (3, 5 or 7)", c.view_size);
+    if (c.view_size < 3 || c.view_size > 11 || c.view_size % 2 == 0)
+        return fail(nullptr, MG_EINVAL, "view_size %d not supported (3, 5, 7, 9 or 11)", c.view_size);
     if (c.max_steps < 1) return fail(nullptr, MG_EINVAL, "max_steps must be positive");
     if (c.num_envs < 1) return fail(nullptr, MG_EINVAL, "num_envs must be positive");
     if (c.batch_envs < 0) return fail(nullptr, MG_EINVAL, "batch_envs must not be negative");
@@ -2901,7 +2929,9 @@ int configure(MgEnv *h, const MgConfig &c) {
     // each wavefront a short critical path.
     const int img = 3 * c.view_size * c.view_size;
     // (CompetativeRedBlueDoor environments act in order, one lane per environment; all others one lane per agent)
-    h->crowd = c.kind != MG_KIND_COMPETITIVE && !c.allow_agent_overlap && c.num_agents >= CROWD_MIN_AGENTS && c.num_agents <= 8;
+    const bool big_view = c.view_size > 7;  // 9 x 9 and 11 x 11 views: the kernel's general forms only (launch_big)
+    h->crowd = c.kind != MG_KIND_COMPETITIVE && !c.allow_agent_overlap && c.num_agents >= CROWD_MIN_AGENTS && c.num_agents <= 8 &&
+               !big_view;
     if (const char *ev = tuning_env("MGRID_CROWD")) h->crowd = h->crowd && atoi(ev) != 0;  // tuning / test override
     auto lds_for = [&](int ne, int g, bool multi = false, int stg = STAGE_LANES) {
         const int et = ne * g, np = ne * c.num_agents;
@@ -2966,7 +2996,7 @@ int configure(MgEnv *h, const MgConfig &c) {
         const int need = lds_for(ne, g, true);
         h->o_multi = kp.o;
         h->o_multi.oh = 0;
-        h->lds_multi = need <= 64 * 1024 ? static_cast<size_t>(need) : 0;
+        h->lds_multi = need <= 64 * 1024 && !big_view ? static_cast<size_t>(need) : 0;
         if (const char *ev = tuning_env("MGRID_MULTI_STEP")) h->multi_enabled = atoi(ev) != 0;  // tuning / test override
     }
     {
@@ -2977,10 +3007,10 @@ int configure(MgEnv *h, const MgConfig &c) {
         // 131072 x 8 agents than 32 and 5 % on 2^20 x 8, where 64 is 6 % slower).  The cell-table variant stays
         // at 32 (16 measured 2 % slower there).
         const int tiles = (c.num_envs + ne * g - 1) / (ne * g);
-        h->stg_step = (h->crowd || c.num_agents > 8) ? 32 : tiles <= 2048 ? 64 : (c.num_agents >= 6 ? 16 : 32);
+        h->stg_step = (h->crowd || c.num_agents > 8 || big_view) ? 32 : tiles <= 2048 ? 64 : (c.num_agents >= 6 ? 16 : 32);
         if (const char *ev = tuning_env("MGRID_STAGE")) {  // tuning / test override
             const int v = atoi(ev);
-            if (!h->crowd && c.num_agents <= 8 && (v == 16 || v == 32 || v == 64)) h->stg_step = v;
+            if (!h->crowd && c.num_agents <= 8 && !big_view && (v == 16 || v == 32 || v == 64)) h->stg_step = v;
         }
         h->lds_step = static_cast<size_t>(lds_for(ne, g, false, h->stg_step));
         if (h->lds_step > 64 * 1024) {  // does not fit: the default width

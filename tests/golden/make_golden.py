@@ -730,6 +730,15 @@ def main():
         ("chaos_single", dict(agents=1, overlap=True, joint=False, succ="all", fail="all", see=False)),
         ("chaos_view5", dict(agents=3, overlap=False, joint=False, succ="all", fail="all", see=False, view=5)),
         ("chaos_view3", dict(agents=2, overlap=True, joint=False, succ="any", fail="all", see=False, view=3)),
+        # views wider than any registered configuration's (the reference takes any odd size, base.py:96)
+        ("chaos_view9", dict(agents=3, overlap=False, joint=False, succ="all", fail="all", see=False, view=9,
+                             size=12, objects=30)),
+        ("chaos_view11", dict(agents=2, overlap=True, joint=True, succ="any", fail="any", see=False, view=11,
+                              size=14, objects=40)),
+        ("chaos_view9_see", dict(agents=4, overlap=False, joint=False, succ="all", fail="any", see=True, view=9,
+                                 size=8, objects=12, terminated=0.2)),
+        ("chaos_view11_see", dict(agents=7, overlap=False, joint=False, succ="all", fail="all", see=True, view=11,
+                                  size=10, objects=20)),
         ("chaos_wide", dict(agents=6, overlap=False, joint=False, succ="all", fail="all", see=False,
                             size=12, objects=30, terminated=0.15)),
     ):
@@ -770,6 +779,9 @@ def main():
                     env.agents[1].state.dir = 0
     record_group("chaos_blockedunlockpickup", lambda: make_env(BlockedUnlockPickupEnv, 2, max_steps=90),
                  16, 80, 43, edit=bup_edit, action_p=BIASED)
+    # (opaque walls seen through 9 x 9 and 11 x 11 views: the rooms' walls and doors shadow most of such a view)
+    record_group("chaos_blockedunlockpickup_view9", lambda: make_env(BlockedUnlockPickupEnv, 2, max_steps=90, view=9),
+                 6, 60, 51, edit=bup_edit, action_p=BIASED)
     # the task played to the end from untouched resets (2 and 3 agents, joint reward on and off)
     record_group("solve_blockedunlockpickup", lambda: make_env(*_ck(cfg["MultiGrid-BlockedUnlockPickup-v0"], 2)),
                  8, 120, 47, policy=solve_blockedunlockpickup)
@@ -797,6 +809,8 @@ def main():
     record_group("chaos_lockedhallway2", lambda: make_env(LockedHallwayEnv, 2, num_rooms=2, max_steps=60,
                                                            joint_reward=False),
                  12, 50, 45, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    record_group("chaos_lockedhallway2_view11", lambda: make_env(LockedHallwayEnv, 3, num_rooms=2, max_steps=60, view=11),
+                 6, 50, 52, edit=lh_edit, action_p=TOGGLY, script=lh_script)
     record_group("chaos_lockedhallway6", lambda: make_env(LockedHallwayEnv, 6, num_rooms=6, max_steps=100),
                  6, 60, 46, edit=lh_edit, action_p=TOGGLY, script=lh_script)
     # ---- CompetativeRedBlueDoorEnvV3, registry entries as they are and with harness-edited starts
@@ -817,6 +831,7 @@ def main():
          {"max_steps": 100, "success_termination_mode": "all", "allow_agent_overlap": True}, 16),
         ("comp_single", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-Red-Single-with-Obstacle", 7, {"max_steps": 60}, 8),
         ("comp_2v2_ctce", "MultiGrid-CompetativeRedBlueDoor-v3-CTCE-2v2", 7, {"max_steps": 80}, 8),
+        ("comp_2v2_view9", "MultiGrid-CompetativeRedBlueDoor-v3-DTDE-2v2-Death-Match", 9, {"max_steps": 90}, 8),
     ):
         cls, kw = cfg[reg]
         kw = dict(kw, **kwx)

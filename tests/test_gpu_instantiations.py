@@ -1,5 +1,5 @@
 """Every instantiation of the tile kernel that the library was built with is launched here, on purpose and against the
-oracle: view sizes 3 / 5 / 7, with and without sight through walls, step / gen_obs / reset, grids known to be walled or
+oracle: view sizes 3 / 5 / 7 / 9 / 11, with and without sight through walls, step / gen_obs / reset, grids known to be walled or
 not, one-hot output, several steps per launch, CompetativeRedBlueDoor steps, the cell-table act phase and the three
 staging widths.  The library's own launch census (mg_launch_census) then has to name every kernel of the build's register
 report (multigrid_amd/kernel_registers.json): an instantiation nothing here reaches is one nobody has checked, and
@@ -149,10 +149,53 @@ def sweep(view, see, monkeypatch):
     env.close()
 
 
+def sweep_wide(view, see):
+    """9 x 9 and 11 x 11 views run the kernel's general forms only: plain steps, gen_obs and reset, the same with
+    one-hot images, CompetativeRedBlueDoor steps; several steps per call are queued as single launches."""
+    rng = np.random.default_rng(100 * view + see)
+    spec, gen = envs.make_spec("MultiGrid-BlockedUnlockPickup-v0", num_agents=4, agent_view_size=view, max_steps=40)
+    spec["see_through_walls"] = bool(see)
+    pool, env, ora = stepper(spec, gen, 330, seed=view)
+    where = f"view {view} see {see}"
+    check_reset(env, ora, pool, rng, where)
+    for _ in range(4):
+        check_step(env, ora, rng, where)
+    check_obs(env, ora, where)
+    check_step_n(env, ora, rng, where)
+    env.close()
+    spec, gen = envs.make_spec("MultiGrid-Empty-Random-6x6-v0", num_agents=7, agent_view_size=view, max_steps=40,
+                               allow_agent_overlap=False, success_termination_mode="all")
+    spec["see_through_walls"] = bool(see)
+    pool, env, ora = stepper(spec, gen, 200, seed=view + 2)
+    check_reset(env, ora, pool, rng, where + " 7 agents")
+    for _ in range(4):
+        check_step(env, ora, rng, where + " 7 agents")
+    env.close()
+    spec, gen = envs.make_spec("MultiGrid-LockedHallway-2Rooms-v0", num_agents=3, agent_view_size=view, max_steps=40)
+    spec["see_through_walls"] = bool(see)
+    pool, env, ora = stepper(spec, gen, 150, seed=view + 1, one_hot=True)
+    check_reset(env, ora, pool, rng, where + " one-hot", one_hot=True)
+    for _ in range(2):
+        check_step(env, ora, rng, where + " one-hot", one_hot=True)
+    check_obs(env, ora, where + " one-hot", one_hot=True)
+    env.close()
+    spec, gen = envs.make_spec(V3 + "DTDE-2v2", agent_view_size=view)
+    spec["see_through_walls"] = bool(see)
+    pool, env, ora = stepper(spec, gen, 330, seed=view + 3)
+    check_reset(env, ora, pool, rng, where + " competitive")
+    for _ in range(3):
+        check_step(env, ora, rng, where + " competitive")
+    check_step_n(env, ora, rng, where + " competitive")
+    env.close()
+
+
 @pytest.mark.parametrize("see", [0, 1])
-@pytest.mark.parametrize("view", [3, 5, 7])
+@pytest.mark.parametrize("view", [3, 5, 7, 9, 11])
 def test_every_dispatch_path_against_the_oracle(view, see, monkeypatch):
-    sweep(view, see, monkeypatch)
+    if view > 7:
+        sweep_wide(view, see)
+    else:
+        sweep(view, see, monkeypatch)
 
 
 def test_zz_every_compiled_instantiation_was_launched(monkeypatch):
@@ -163,6 +206,9 @@ def test_zz_every_compiled_instantiation_was_launched(monkeypatch):
         for view in (3, 5, 7):
             for see in (0, 1):
                 sweep(view, see, monkeypatch)
+        for view in (9, 11):
+            for see in (0, 1):
+                sweep_wide(view, see)
     launched = set(_lib.launch_census())
     names = "V,SEE,MODE,WALLED,OH,MULTI,COMP,CROWD,STG"
     never = sorted(compiled - launched)
