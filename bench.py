@@ -402,13 +402,14 @@ def pyref_rate(cfg_id, seconds):
 
 
 def cpu_leg(cfg_id, seconds=10.0):
-    """The reference-style Python step loop (oracle/pyref.py, one env, one core) and the C port."""
+    """The C restatement of the reference's step (oracle/mg_oracle.c) on one host core - the reported baseline - and
+    beside it the same on every core, and the reference-style Python step loop (oracle/pyref.py, one environment)."""
     import numpy as np
 
     from multigrid_amd import envs
     from oracle.coracle import BatchOracle
 
-    py_rate, n, name, agents = pyref_rate(cfg_id, seconds)
+    py_rate, n, name, agents = pyref_rate(cfg_id, 5.0)
     py1_rate, n1, name1, agents1 = pyref_rate(1, 4.0)
     _, _, _, _, kw = CONFIGS[cfg_id]
     spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
@@ -422,7 +423,7 @@ def cpu_leg(cfg_id, seconds=10.0):
     order = np.argsort(rng.random(size=(8, e, agents)), axis=-1).astype(np.uint8)
     m = 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 4.0:
+    while time.perf_counter() - t0 < seconds:
         bo.step(acts[m % 8], order[m % 8])
         done = (bo.terminated.all(axis=1) | bo.truncated.all(axis=1))
         if done.any():
@@ -459,15 +460,18 @@ def cpu_leg(cfg_id, seconds=10.0):
         t.join()
     c_all_rate = sum(counts) * e * agents / (time.perf_counter() - t0)
     return dict(
-        value=py_rate, unit="agent-steps/s", cores=1, kind="port",
-        sample=f"{n} steps of one {name} env ({agents} agents, uniform-random actions) through the Python "
-               f"restatement of the reference step loop (oracle/pyref.py, vectorised gen_obs), {seconds:.0f} s",
-        config1_plumbing_value=py1_rate, config1_plumbing_cores=1,
-        config1_plumbing_sample=f"{n1} steps of one {name1} env ({agents1} agents), same loop, 4 s (BASELINE configs[0])",
-        c_port_value=c_rate, c_port_cores=1,
-        c_port_sample=f"{m} batched steps of {e} envs through oracle/mg_oracle.c (gcc -O2, one thread)",
-        c_port_all_cores_value=c_all_rate, c_port_all_cores=cores,
-        c_port_all_cores_sample=f"{sum(counts)} batched steps of {e} envs over {cores} threads, 4 s")
+        value=c_rate, unit="agent-steps/s", cores=1, kind="port",
+        sample=f"{m} batched steps of {e} {name} envs ({agents} agents, uniform-random actions, finished episodes "
+               f"restarted) through the C restatement of the reference's step (oracle/mg_oracle.c, gcc -O2, one "
+               f"thread), {seconds:.0f} s",
+        all_cores_value=c_all_rate, all_cores=cores,
+        all_cores_sample=f"{sum(counts)} batched steps of {e} envs over {cores} threads, 4 s",
+        python_port_value=py_rate, python_port_cores=1,
+        python_port_sample=f"{n} steps of one {name} env through the Python restatement of the reference's step loop "
+                           f"(oracle/pyref.py, vectorised gen_obs), 5 s",
+        config1_python_port_value=py1_rate, config1_python_port_cores=1,
+        config1_python_port_sample=f"{n1} steps of one {name1} env ({agents1} agents), same Python loop, 4 s "
+                                   f"(BASELINE configs[0])")
 
 
 def parse_args(argv=None):
