@@ -828,6 +828,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     uint8_t *h = lds + p.o.hdr + (s0 + my_slot) * p.HP;
     uint8_t *a = h + H_ROWS + 8 * my_agent;
     uint2 *pair = reinterpret_cast<uint2 *>(lds + p.o.img);
+    MG_EXP(unsigned long long x0 = __builtin_amdgcn_s_memtime(), x1 = 0, x2 = 0, x3 = 0, x4 = 0;)
     uint2 r0 = make_uint2(0u, 0u);
     ActEval ev;
     ev.r = r0;
@@ -1026,6 +1027,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     }
     const uint64_t group = (A == 64 ? ~0ull : ((1ull << A) - 1ull)) << (my_slot * A);
     const int kind = p.kind();
+    MG_EXP(x1 = __builtin_amdgcn_s_memtime();)
     finish_action(p, ev, r0, occupied);
     const bool final_here = mine && !clash;
     // (what happens in few steps - cells written, goals reached, hook events - is first asked of the whole wavefront:
@@ -1044,6 +1046,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
     uint32_t my_term = (r0.x >> 24) | ((final_here && (ev.bits & EV_TERM)) ? 1u : 0u);
     bool my_goal = final_here && (ev.bits & EV_GOAL);
     if (final_here && (ev.bits & EV_ALIVE) && (ev.r.x != r0.x || ev.r.y != r0.y)) *reinterpret_cast<uint2 *>(a) = ev.r;
+    MG_EXP(x2 = __builtin_amdgcn_s_memtime();)
     const uint64_t left = __ballot(clash);  // marked agents: they act one by one, in the order of base.py:457-464
     const bool replayed = (left & group) != 0;
     if (left != 0) {
@@ -1107,12 +1110,14 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
             }
         }
         if (resync & group) flags &= ~FLAG_STALE;
+        MG_EXP(x3 = __builtin_amdgcn_s_memtime();)
         uint64_t acted = 0;  // marked agents that have had their turn
 #pragma unroll 1
         for (int n = 0; n < A; ++n) {  // base.py:464
             const bool turn = clash && pos == n;
             const uint64_t now = __ballot(turn);
             if (now == 0) continue;
+            MG_EXP(if (p.dbg_buf && threadIdx.x == 0) p.dbg_buf[static_cast<size_t>(blockIdx.x) * 32 + 26] += 1;)
             if (turn) {
                 // The first marked agent of an environment acts on the state the step began with (what the unmarked
                 // agents did does not concern it): its evaluation from above stands.  The others see what the marked
@@ -1150,6 +1155,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         }
     }
     if (resync & group) flags &= ~FLAG_STALE;
+    MG_EXP(x4 = __builtin_amdgcn_s_memtime();)
 
     // ---- the rest of the step, the environment's lanes agreeing through ballots ---------------------------
     // The hooks look at the state the actions left (they run after gen_obs in the reference, on the returned
@@ -1231,6 +1237,24 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
             }
         }
     }
+    MG_EXP(
+    if (p.dbg_buf) {  // which of the rare paths this wavefront took (diagnostic builds)
+        const uint64_t b_un = __ballot(unstable), b_wr = __ballot(mine && nlog > 0), b_pay = __ballot(mine && my_rewm != 0);
+        const uint64_t b_cl = __ballot(clash);
+        if (threadIdx.x == 0) {
+            unsigned long long *d = p.dbg_buf + static_cast<size_t>(blockIdx.x) * 32;
+            d[27] += b_wr != 0;
+            d[28] += b_pay != 0;
+            d[29] += b_un != 0;
+            d[24] += __popcll(b_cl);
+            d[11] += x1 - x0;                       // rows in, first evaluation, marking
+            d[12] += x2 - x1;                       // finish, log, rows out
+            d[13] += b_cl ? x3 - x2 : 0;            // order and places (wavefronts with marked agents)
+            d[14] += b_cl ? x4 - x3 : x4 - x2;      // the rounds
+            d[15] = x4;                             // (the rest of act_lanes runs from here to stamp 2)
+        }
+    }
+    )
     {
         bool all_term = false;
         if (const uint64_t touts = __ballot(mine && my_tout != 0)) all_term = (touts & group) == group;

@@ -35,10 +35,25 @@ def run(cfg, agents, e, **kw):
         print(f"   life   (min / median / p90 / p99 / max): {q(life)} clk")
     print(f"{cfg} A={agents} E={e} tiles={nt.value} tile={os.environ.get('MGRID_TILE','auto')}: mean wave lifetime {total:.0f} clk")
     prev = 0
+    life = b[:, 10] - b[:, 0]
+    slow = life >= np.percentile(life, 97)  # the slowest wavefronts: where do they lose their time?
     for k in range(1, 11):
-        d = (b[:, k] - b[:, prev]).mean()
-        print(f"   {NAMES[k]:28s} {d:9.0f} clk  {100*d/total:5.1f}%")
+        ph = b[:, k] - b[:, prev]
+        d = ph.mean()
+        print(f"   {NAMES[k]:28s} {d:9.0f} clk  {100*d/total:5.1f}%   median {np.median(ph):6.0f}  p99 {np.percentile(ph, 99):6.0f}"
+              f"  max {ph.max():6.0f}   slowest 3 % of wavefronts: {ph[slow].mean():6.0f}")
         prev = k
+    if not int(os.environ.get("MGRID_DBG", "0")) & 16:
+        act = b[:, 2] - b[:, 1]
+        print("   act phase by what the wavefront met (slots 24, 26-29 of the diagnostic buffer):")
+        rep = b[:, 26] > 0
+        for nm, col in (("rows in, first evaluation, marking", 11), ("finish, log, rows out", 12), ("order and places", 13), ("rounds", 14)):
+            print(f"     {nm:36s} no marked agents {b[~rep, col].mean():6.0f} clk   with marked agents {b[rep, col].mean() if rep.any() else 0:6.0f} clk")
+        tail = b[:, 2] - b[:, 15]
+        print(f"     {'hooks, flags, write-back (last call)':36s} no marked agents {tail[~rep].mean():6.0f} clk   with marked agents {tail[rep].mean() if rep.any() else 0:6.0f} clk")
+        for name, col in (("replay rounds", 26), ("marked agents", 24), ("cells written", 27), ("rewards", 28), ("unstable", 29)):
+            vals = np.unique(b[:, col])
+            print(f"     {name:14s}: " + "  ".join(f"{int(v)}: {act[b[:, col] == v].mean():.0f} clk ({(b[:, col] == v).mean()*100:.0f} %)" for v in vals[:10]))
     if int(os.environ.get("MGRID_DBG", "0")) & 16:
         n = b[:, 19].sum()
         print(f"   light ticks per wave: staging {b[:,20].mean():.0f}  act {b[:,21].mean():.0f}  same-step restarts {b[:,22].mean():.0f}  whole {b[:,23].mean():.0f} clk")
