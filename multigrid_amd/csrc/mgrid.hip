@@ -5,11 +5,12 @@
 // One 64-lane wavefront (= one workgroup) owns G sub-tiles of NE consecutive environments each, with
 // NE * A <= 64 agent lanes per sub-tile, and runs four phases on them, all through LDS:
 //   stage    the header blocks and the first sub-tile's grids are copied HBM -> LDS with 16-byte loads;
-//   act      with six or more agents per environment, one lane per AGENT works out its action against
-//            the state at the start of the step; only the agents whose actions could interact are left
-//            for one lane per ENVIRONMENT to replay in the given order (the reference's sequential
-//            handle_actions loop), which also runs the environment hook; with fewer agents the
-//            in-order form does everything;
+//   act      one lane per AGENT works out its action against the state at the start of the step; the few
+//            agents whose actions could interact are marked and then take their turns in the lanes, in
+//            the environment's order (the reference's sequential handle_actions loop, run only for the
+//            agents it matters for); the environment hook and the step's bookkeeping are settled by the
+//            environment's lanes through ballots.  CompetativeRedBlueDoor steps keep one lane per
+//            ENVIRONMENT, whose agents act in the caller's order;
 //   observe  one lane per AGENT walks its V x V view over the LDS grid, runs the visibility
 //            scan on 7-bit row masks in registers and keeps the image in registers;
 //   write    the images pass through an LDS buffer that mirrors the output tensor and leave as aligned

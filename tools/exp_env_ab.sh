@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one environment switch of the library on chosen workloads, on one box:
-#   tools/exp_env_ab.sh MGRID_LANES_ACT "0 1 default" "2 1" "3 1" "5 8" ...   (config, steps per launch, extra flags)
+#   tools/exp_env_ab.sh MGRID_STAGE "16 32 64 default" "2 1" "3 1" "5 8" ...   (config, steps per launch, extra flags)
 set -e
 export MGRID_TUNING=1  # the library reads its tuning switches only with this opt-in
 var=$1; vals=$2; shift 2
