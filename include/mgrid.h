@@ -18,7 +18,10 @@
  *                                (the AgentState row of multigrid/core/agent.py:266-275 without
  *                                its constant type column, position first)
  *   meta     uint8 [E][4]        RedBlueDoors: red_x red_y blue_x blue_y (multigrid/envs/
- *                                redbluedoors.py:161-168); zeros for the other kinds
+ *                                redbluedoors.py:161-168); LockedHallway with more than six rooms:
+ *                                meta[0..1] = doors already rewarded (bit 2 * row + side), meta[3] = number
+ *                                of distinct door colours (mg_upload_layouts counts them itself);
+ *                                zeros for the other kinds
  *   image    uint8 [E][A][V][V][3]  obs["image"] of multigrid/base.py:430-436 (int64 there)
  *   onehot   uint8 [E][A][V][V][24] the same image one-hot encoded, multigrid/wrappers.py:114-146
  * Cell fields (and the carried object and colour of an agent row) are limited to type < 16, state < 16,
@@ -77,9 +80,12 @@ typedef struct MgConfig {
     int32_t joint_reward;        /*                                      base.py:98 */
     int32_t success_any;         /* success_termination_mode == "any"    base.py:99 */
     int32_t failure_any;         /* failure_termination_mode == "any"    base.py:100 */
-    int32_t num_rooms;           /* LockedHallway only, 1..6: rewarded doors are tracked by door colour and
-                                    the reference has six colours (it cycles them beyond six rooms,
-                                    which is not supported: MG_EINVAL)    locked_hallway.py:129,160-166 */
+    int32_t num_rooms;           /* LockedHallway only, 1..14.  Up to six rooms every door has a colour of its
+                                    own and rewarded doors are tracked by colour; beyond that the reference
+                                    cycles the six colours, doors of one colour are separate doors, tracked by
+                                    room (which takes its room-grid geometry: width = 3 (room_size - 1) + 1,
+                                    height = num_rooms / 2 * (room_size - 1) + 1), and the all-doors ending
+                                    comes at the number of distinct colours  locked_hallway.py:129,150-166,213 */
     int32_t num_envs;            /* E: environments held by this handle */
     int32_t device;              /* HIP device ordinal */
     int32_t autoreset;           /* MG_AUTORESET_* */
@@ -236,7 +242,7 @@ int mg_gen_obs_of_state(const MgConfig *cfg, const uint8_t *grid_dev, const uint
 
 /* Debug / parity access to the full state in the reference's layouts (see the top of this file).
  * steps int32[E] = step_count (base.py:350,395); flags uint8[E]: bits 0-5 LockedHallway doors
- * already rewarded, by door colour (locked_hallway.py:204-205); bit 7: RedBlueDoors blue door
+ * already rewarded, by door colour (locked_hallway.py:204-205; with more than six rooms they are in meta); bit 7: RedBlueDoors blue door
  * object re-closed after a failure while its grid cell still reads open (redbluedoors.py:185).
  * MG_KIND_COMPETITIVE keeps there what the reference keeps in objects: flags bit 0 / 1 = the red / blue key
  * object is "picked up" (competative_red_blue_door.py:434-435) although the agent row still shows the copy

@@ -846,6 +846,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         blue_xy = hm.y >> 16;
         ev = eval_action(p, r0, w0, my_act, flags, blue_xy);
     }
+    uint32_t lh_doors = red_xy, lh_distinct = blue_xy >> 8;  // LockedHallway with more than six rooms: meta[0..1], meta[3]
     const bool need_occ = mine && needs_occupancy(p, ev);
     bool occupied = false, clash = false, unstable = false;
     // when nobody may write a cell and nobody asks where the others stand (the usual case in open
@@ -1197,25 +1198,51 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
             }
         }
     } else if (kind == MG_KIND_LOCKEDHALLWAY) {
-        uint32_t lh_bit = 0;  // colour bit of the unlocked door I toggle towards
+        // Up to six rooms: one door colour each, a door is its colour (flags bits 0-5).  More rooms: colours repeat
+        // (locked_hallway.py:150-151), a door is its room - 2 * row + side - in a 16-bit set kept in meta[0..1], and
+        // the all-doors ending is reached at the number of DISTINCT colours, meta[3] (`self.rooms` is keyed by colour,
+        // :160-166, :213).
+        const bool many = p.num_rooms() > 6;
+        uint32_t lh_bit = 0;  // the unlocked door I toggle towards
         if (toggles && (ev.fxy & 0xFF) < static_cast<uint32_t>(p.W()) && (ev.fxy >> 8) < static_cast<uint32_t>(p.H())) {
             const uint32_t wa = cell_at_end(ev.ci, w0);
-            if ((wa & 15) == T_DOOR && ((wa >> 4) & 15) != S_LOCKED) lh_bit = (1u << ((wa >> 8) & 7)) & FLAG_LH_MASK;
+            if ((wa & 15) == T_DOOR && ((wa >> 4) & 15) != S_LOCKED) {
+                if (!many) {
+                    lh_bit = (1u << ((wa >> 8) & 7)) & FLAG_LH_MASK;
+                } else {
+                    const uint32_t pitch = static_cast<uint32_t>(p.W() - 1) / 3u;  // room_size - 1
+                    const uint32_t row = min((ev.fxy >> 8) / pitch, static_cast<uint32_t>(p.num_rooms() / 2 - 1));
+                    lh_bit = 1u << (2u * row + ((ev.fxy & 0xFF) > static_cast<uint32_t>(p.W() / 2) ? 1u : 0u));
+                }
+            }
         }
         if (__ballot(lh_bit != 0)) {
             uint32_t newbits = 0, first = 0;
+            if (!many) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const uint64_t m = __ballot(lh_bit == (1u << c)) & group;
-                if (m != 0 && !(flags & (1u << c))) {
-                    newbits |= 1u << c;
-                    if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+                for (int c = 0; c < 6; ++c) {
+                    const uint64_t m = __ballot(lh_bit == (1u << c)) & group;
+                    if (m != 0 && !(flags & (1u << c))) {
+                        newbits |= 1u << c;
+                        if (lh_bit == (1u << c) && __builtin_ctzll(m) == lane) first = 1;  // lowest index: locked_hallway.py:200
+                    }
                 }
+                flags |= newbits;
+            } else {
+                const uint32_t fresh = lh_bit & ~lh_doors;
+                first = fresh != 0 ? 1u : 0u;
+#pragma unroll 1
+                for (int k = 0; k < A; ++k) {  // the environment's agents in index order
+                    const uint32_t other = static_cast<uint32_t>(__shfl(static_cast<int>(fresh), my_slot * A + k));
+                    newbits |= other;
+                    if (k < my_agent && other == fresh) first = 0;  // a lower index toggles towards the same door
+                }
+                lh_doors |= newbits;
             }
             my_rewm += p.joint() ? static_cast<uint32_t>(__popc(newbits)) : first;  // `+=`, locked_hallway.py:207-211
-            flags |= newbits;
         }
-        if (__popc(flags & FLAG_LH_MASK) == p.num_rooms()) my_tout = 1;  // only the returned dict, :213-215
+        if (many ? __popc(lh_doors) == static_cast<int>(lh_distinct) : __popc(flags & FLAG_LH_MASK) == p.num_rooms())
+            my_tout = 1;  // only the returned dict, :213-215
     } else if (kind == MG_KIND_REDBLUEDOORS) {
         const bool cand = toggles && ev.fxy == blue_xy;
         if (const uint64_t cands_any = __ballot(cand)) {
@@ -1265,7 +1292,7 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
         int paid = 0;
         if (__ballot(mine && my_rewm != 0))
             paid = __popcll(__ballot(mine && (my_rewm & 1)) & group) + 2 * __popcll(__ballot(mine && (my_rewm & 2)) & group) +
-                   4 * __popcll(__ballot(mine && (my_rewm & 4)) & group);
+                   4 * __popcll(__ballot(mine && (my_rewm & 4)) & group) + 8 * __popcll(__ballot(mine && (my_rewm & 8)) & group);
         if (mine) {
             lds[p.o.oterm + s0 * A + lane] = static_cast<uint8_t>(my_term);  // what gen_obs sees (base.py:399)
             lds[p.o.tout + s0 * A + lane] = static_cast<uint8_t>(my_tout);
@@ -1290,6 +1317,8 @@ __device__ __forceinline__ void act_lanes(const KParams &p, uint8_t *lds, int en
                 const double R = paid != 0 ? step_reward(p, step) : 0.0;  // nobody paid: every reward is 0 * R
                 *reinterpret_cast<int *>(h + H_STEP) = step;
                 h[H_FLAGS] = static_cast<uint8_t>(flags | (over ? FLAG_OVER : 0u));
+                if (kind == MG_KIND_LOCKEDHALLWAY && p.num_rooms() > 6)
+                    *reinterpret_cast<uint16_t *>(h + H_META) = static_cast<uint16_t>(lh_doors);
                 reinterpret_cast<double *>(lds + p.o.R)[s0 + my_slot] = R;
                 *reinterpret_cast<uint32_t *>(lds + p.o.flag + 4 * (s0 + my_slot)) =
                     (trunc ? 1u : 0u) | (will_reset ? 0x100u : 0u) | (static_cast<uint32_t>(nlog) << 16);
@@ -2588,7 +2617,7 @@ __global__ void mg_generate_layouts_kernel(KParams p, MgLayoutSpec ls, uint8_t *
     } else {  // locked_hallway.py:146-184
         const int rs = ls.size, nrooms = p.num_rooms(), nrows = nrooms / 2;
         G.rooms(rs, nrows, 3);
-        uint8_t seq[12], doors[6];
+        uint8_t seq[18], doors[14];
         const int reps = (nrooms + 5) / 6;
         for (int i = 0; i < 6 * reps; ++i) seq[i] = static_cast<uint8_t>(i % 6);
         G.shuffle(seq, 6 * reps);
@@ -2625,6 +2654,11 @@ __global__ void mg_generate_layouts_kernel(KParams p, MgLayoutSpec ls, uint8_t *
             key_index = stop;
         }
         for (int k = 0; k < A; ++k) G.place_agent(k, rs - 1, 0, rs, H);
+        if (nrooms > 6) {  // the number of distinct door colours, where the all-doors ending is reached (:160-166,213)
+            uint32_t colours = 0;
+            for (int i = 0; i < nrooms; ++i) colours |= 1u << seq[i];
+            meta = static_cast<uint32_t>(__popc(colours)) << 24;
+        }
     }
     // header block: door positions and the cells in front of the agents (kept current by the step kernel)
     *reinterpret_cast<uint32_t *>(hd + H_META) = meta;
@@ -2914,8 +2948,14 @@ int configure(MgEnv *h, const MgConfig &c) {
     if (c.batch_envs < 0) return fail(nullptr, MG_EINVAL, "batch_envs must not be negative");
     if (c.autoreset < 0 || c.autoreset > MG_AUTORESET_NEXT_STEP)
         return fail(nullptr, MG_EINVAL, "unknown autoreset mode %d", c.autoreset);
-    if (c.kind == MG_KIND_LOCKEDHALLWAY && (c.num_rooms < 1 || c.num_rooms > 6))
-        return fail(nullptr, MG_EINVAL, "LockedHallway needs 1..6 rooms (one door colour each), got %d", c.num_rooms);
+    if (c.kind == MG_KIND_LOCKEDHALLWAY && (c.num_rooms < 1 || c.num_rooms > 14))
+        return fail(nullptr, MG_EINVAL, "LockedHallway needs 1..14 rooms, got %d", c.num_rooms);
+    // more than six rooms: door colours repeat and a door is told by the room it belongs to, which takes the RoomGrid
+    // geometry of locked_hallway.py:138-145 (three columns of rooms, num_rooms / 2 rows, shared walls)
+    if (c.kind == MG_KIND_LOCKEDHALLWAY && c.num_rooms > 6 &&
+        (c.num_rooms % 2 != 0 || c.width < 10 || (c.width - 1) % 3 != 0 || c.height != (c.num_rooms / 2) * ((c.width - 1) / 3) + 1))
+        return fail(nullptr, MG_EINVAL, "LockedHallway with %d rooms needs an even number of rooms on a %d-row, 3-column room grid, got %dx%d",
+                    c.num_rooms, c.num_rooms / 2, c.width, c.height);
 
     h->cfg = c;
     KParams &kp = h->kp;
@@ -3144,6 +3184,14 @@ int mg_upload_layouts(MgHandle h, const uint8_t *grids, const uint8_t *agents, c
             for (int y = 0; y < kp.H(); ++y)
                 if ((x == 0 || y == 0 || x == kp.W() - 1 || y == kp.H() - 1) && gd[x * kp.H() + y] != CELL_WALL) walled = false;
         if (meta) memcpy(hd + H_META, meta + static_cast<size_t>(l) * 4, 4);
+        if (kp.kind() == MG_KIND_LOCKEDHALLWAY && kp.num_rooms() > 6) {
+            // no doors paid yet; the all-doors ending comes at the number of distinct door colours (locked_hallway.py:160-166,213)
+            uint32_t colours = 0;
+            for (int c = 0; c < cells; ++c)
+                if ((gd[c] & 15) == T_DOOR) colours |= 1u << ((gd[c] >> 8) & 15);
+            hd[H_META] = hd[H_META + 1] = hd[H_META + 2] = 0;
+            hd[H_META + 3] = static_cast<uint8_t>(__builtin_popcount(colours));
+        }
         const uint8_t *ar = agents + static_cast<size_t>(l) * A * 8;
         for (int k = 0; k < A; ++k) {
             if (ar[8 * k + R_X] >= kp.W() || ar[8 * k + R_Y] >= kp.H() || ar[8 * k + R_DIR] > 3)

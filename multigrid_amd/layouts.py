@@ -240,7 +240,10 @@ def gen_lockedhallway(num_rooms: int, agent_colors: Sequence[int], mixin_rng, en
             key_index += 1
     for k in range(len(agent_colors)):
         b.place_agent(k, hallway_top, hallway_size)
-    return b.finish(mission="open all the doors")
+    # beyond six rooms door colours repeat: meta[3] = len(self.rooms), the number of distinct door colours, at which
+    # the all-doors ending is reached (locked_hallway.py:160-166,213); meta[0..1] = the doors paid so far (none)
+    meta = (0, 0, 0, len(room_of)) if num_rooms > len(COLOR_NAMES) else (0, 0, 0, 0)
+    return b.finish(meta=meta, mission="open all the doors")
 
 
 def gen_competitive(size: int, agent_colors: Sequence[int], mixin_rng, env_rng=None, team_colors: Sequence[int] = (RED,),

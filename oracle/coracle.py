@@ -38,8 +38,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
+        build()  # (compiles only when the library is missing or older than its source)
         _lib = ctypes.CDLL(LIB_PATH)
         p = ctypes.c_void_p
         _lib.mgo_gen_obs.argtypes = [ctypes.POINTER(CSpec), ctypes.c_int64, p, p, p]

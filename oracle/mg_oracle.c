@@ -362,12 +362,6 @@ static void handle_actions(env_t *e, const uint8_t *actions, const uint8_t *orde
     }
 }
 
-static int popcount6(unsigned m) {
-    int n = 0;
-    for (int b = 0; b < 6; ++b) n += (m >> b) & 1;
-    return n;
-}
-
 /* MultiGridEnv.step (base.py:364-408) followed by the subclass hook */
 static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, uint8_t *meta, int32_t *steps,
                      uint8_t *flags, const uint8_t *actions, const uint8_t *order, uint8_t *image,
@@ -412,6 +406,12 @@ static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, uint8_t
         for (int i = 0; i < A; ++i)
             if (agents[8 * i + ACT] == T_BOX) on_success(&e, i, terminated);
     } else if (sp->kind == K_LOCKEDHALLWAY) { /* locked_hallway.py:200-215 */
+        /* `unlocked_doors` holds door objects (:204-205).  Up to six rooms a door is told by its colour (flags bits
+         * 0-5); beyond that colours repeat (:150-151) and a door is told by its room, 2 * row + side, in a 16-bit set
+         * kept in meta[0..1]; the all-doors ending then compares with the number of distinct door colours, meta[3]
+         * (`self.rooms` is keyed by colour, :160-166, :213). */
+        const int many = sp->num_rooms > 6;
+        unsigned doors = many ? (unsigned)(e.meta[0] | (e.meta[1] << 8)) : (unsigned)(e.flags & 0x3F);
         for (int i = 0; i < A; ++i) {
             if (actions[i] != A_TOGGLE) continue;
             const uint8_t *ag = agents + 8 * i;
@@ -419,15 +419,32 @@ static void step_one(const mgo_spec *sp, uint8_t *grid, uint8_t *agents, uint8_t
             if (fx < 0 || fx >= sp->width || fy < 0 || fy >= sp->height) continue;
             const uint8_t *c = cell(&e, fx, fy);
             if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;
-            const unsigned bit = 1u << (c[1] & 7);
-            if (e.flags & bit) continue;
-            e.flags |= (uint8_t)bit;
+            unsigned bit;
+            if (many) {
+                const int pitch = (sp->width - 1) / 3; /* room_size - 1 */
+                int row = fy / pitch;
+                if (row > sp->num_rooms / 2 - 1) row = sp->num_rooms / 2 - 1;
+                bit = 1u << (2 * row + (fx > sp->width / 2 ? 1 : 0));
+            } else {
+                bit = 1u << (c[1] & 7);
+                if (!(bit & 0x3F)) continue;
+            }
+            if (doors & bit) continue;
+            doors |= bit;
             if (sp->joint_reward)
                 for (int k = 0; k < A; ++k) reward[k] += reward_now(&e);
             else
                 reward[i] += reward_now(&e);
         }
-        if (popcount6(e.flags & 0x3F) == sp->num_rooms)
+        if (many) {
+            e.meta[0] = (uint8_t)(doors & 0xFF);
+            e.meta[1] = (uint8_t)(doors >> 8);
+        } else {
+            e.flags = (uint8_t)((e.flags & ~0x3F) | doors);
+        }
+        int opened = 0;
+        for (unsigned m = doors; m; m &= m - 1) ++opened;
+        if (opened == (many ? e.meta[3] : sp->num_rooms))
             for (int k = 0; k < A; ++k) terminated[k] = 1;
     }
     *steps = e.steps;

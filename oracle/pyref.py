@@ -308,6 +308,8 @@ class Env:
         # LockedHallway: doors already rewarded, as a bit per door colour
         # (locked_hallway.py:190,204-205; door colours are distinct for <= 6 rooms)
         self.unlocked_mask = 0
+        self.unlocked_at = set()
+        self.door_colours = 0
         # RedBlueDoors: the blue Door OBJECT was re-closed after a failure while
         # its grid cell still reads open (redbluedoors.py:185 has no grid.update)
         self.blue_stale_open = False
@@ -322,6 +324,9 @@ class Env:
         self.meta[...] = 0 if meta is None else meta
         self.step_count = 0  # base.py:350
         self.unlocked_mask = 0  # locked_hallway.py:190
+        self.unlocked_at = set()
+        doors = self.grid[..., 0] == DOOR  # len(self.rooms), locked_hallway.py:160-166
+        self.door_colours = len(set(self.grid[..., 1][doors].tolist()))
         self.blue_stale_open = False
         self.flags = 0
         return self.gen_obs()
@@ -489,19 +494,29 @@ class Env:
                 if self.agents[i, CT] == BOX:
                     self.on_success(i, rewards, terminations)
         elif sp.kind == KIND_LOCKEDHALLWAY:  # locked_hallway.py:200-215
+            # `unlocked_doors` holds door OBJECTS (:204-205).  Up to six rooms every door has a colour of its own and
+            # is told by it; beyond that colours repeat (:150-151) and a door is told by where it stands.  `self.rooms`
+            # is keyed by colour (:160-166), so the all-doors ending compares with the number of DISTINCT colours (:213).
+            many = sp.num_rooms > 6
             for i in range(sp.num_agents):
                 if int(actions[i]) == TOGGLE:
                     fx, fy = self._front(i)
                     if self.grid[fx, fy, 0] == DOOR and self.grid[fx, fy, 2] != LOCKED:
-                        bit = 1 << int(self.grid[fx, fy, 1])
-                        if not self.unlocked_mask & bit:
+                        if many:
+                            new = (fx, fy) not in self.unlocked_at
+                            self.unlocked_at.add((fx, fy))
+                        else:
+                            bit = 1 << int(self.grid[fx, fy, 1])
+                            new = not self.unlocked_mask & bit
                             self.unlocked_mask |= bit
+                        if new:
                             if sp.joint_reward:
                                 for k in rewards:
                                     rewards[k] += self._reward()
                             else:
                                 rewards[i] += self._reward()
-            if bin(self.unlocked_mask).count("1") == sp.num_rooms:
+            opened = len(self.unlocked_at) if many else bin(self.unlocked_mask).count("1")
+            if opened == (self.door_colours if many else sp.num_rooms):
                 for i in range(sp.num_agents):
                     terminations[i] = True
         return obs, rewards, terminations, truncations, {}

@@ -89,6 +89,10 @@ def door_meta(env) -> np.ndarray:
                 meta[0], meta[1] = x, y
             if obj is env.blue_door:
                 meta[2], meta[3] = x, y
+    if isinstance(env, LockedHallwayEnv) and env.num_rooms > 6:
+        # door colours repeat beyond six rooms (locked_hallway.py:150-151): the all-doors ending compares with
+        # len(self.rooms), a dict keyed by colour (:160-166, :213)
+        meta[3] = len(env.rooms)
     return meta
 
 
@@ -811,6 +815,14 @@ def main():
                  12, 50, 45, edit=lh_edit, action_p=TOGGLY, script=lh_script)
     record_group("chaos_lockedhallway2_view11", lambda: make_env(LockedHallwayEnv, 3, num_rooms=2, max_steps=60, view=11),
                  6, 50, 52, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    # more rooms than door colours: doors of one colour are separate doors, the ending comes at len(self.rooms)
+    record_group("chaos_lockedhallway8", lambda: make_env(LockedHallwayEnv, 4, num_rooms=8, room_size=4, max_steps=120),
+                 10, 70, 53, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    record_group("chaos_lockedhallway10", lambda: make_env(LockedHallwayEnv, 3, num_rooms=10, room_size=4, max_steps=90,
+                                                            joint_reward=False),
+                 6, 60, 54, edit=lh_edit, action_p=TOGGLY, script=lh_script)
+    record_group("solve_lockedhallway8", lambda: make_env(LockedHallwayEnv, 2, num_rooms=8, room_size=4, max_steps=2000),
+                 4, 700, 55, policy=solve_lockedhallway, extra_after_done=400)
     record_group("chaos_lockedhallway6", lambda: make_env(LockedHallwayEnv, 6, num_rooms=6, max_steps=100),
                  6, 60, 46, edit=lh_edit, action_p=TOGGLY, script=lh_script)
     # ---- CompetativeRedBlueDoorEnvV3, registry entries as they are and with harness-edited starts

@@ -40,7 +40,7 @@ def test_bad_arguments_fail_without_a_gpu():
     assert b"view_size" in L.mg_last_error(None)
     cfg.view_size = 13
     assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"view_size" in L.mg_last_error(None)
-    cfg = _lib.MgConfig(kind=3, width=13, height=9, num_agents=2, view_size=7, max_steps=10, num_envs=4, num_rooms=8)
+    cfg = _lib.MgConfig(kind=3, width=13, height=9, num_agents=2, view_size=7, max_steps=10, num_envs=4, num_rooms=8)  # 8 rooms need 13 x 17
     assert L.mg_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"LockedHallway" in L.mg_last_error(None)
     cfg = _lib.MgConfig(kind=0, width=8, height=8, num_agents=2, view_size=7, max_steps=10, num_envs=4, batch_envs=-1)

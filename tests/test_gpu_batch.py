@@ -172,6 +172,62 @@ def test_autoreset_modes(case, mode):
     env.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("rooms,room_size,agents,joint", [(8, 4, 4, True), (10, 5, 3, False), (14, 5, 6, True)])
+def test_lockedhallway_with_more_rooms_than_door_colours(rooms, room_size, agents, joint, mode):
+    """Beyond six rooms door colours repeat (locked_hallway.py:150-151): doors of one colour are separate doors that
+    each pay once, and the all-doors ending is reached at the number of DISTINCT colours (:160-166, :213).  Half of
+    the environments start with every door unlocked and the agents toggle a lot, so that doors pay all the time."""
+    from multigrid_amd.batched import BatchedMultiGrid
+    from oracle.coracle import BatchOracle
+    e, n_l = 2000, 48
+    spec, gen = envs.make_spec("MultiGrid-LockedHallway-6Rooms-v0", num_agents=agents, num_rooms=rooms, room_size=room_size,
+                               max_steps=45, joint_reward=joint, agent_view_size=5)  # (rooms of 2 x 2 cells cannot hold the keys
+    # of three doors of one colour: the reference's place_obj would then never return, locked_hallway.py:176-181)
+    pool = list(layouts.make_pool(gen, n_l, seed0=3)[:3])
+    assert (pool[2][:, 3] >= 4).all() and (pool[2][:, 3] <= 6).all()
+    doors = pool[0][..., 0] == 4
+    pool[0][::2][doors[::2], 2] = 1  # closed instead of locked: a toggle opens them
+    env = BatchedMultiGrid(spec, e, device=0, autoreset=mode)
+    env.upload_layouts(pool[0], pool[1], pool[2])
+    ora = BatchOracle(spec, e)
+    rng = np.random.default_rng(rooms)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    env.reset()
+    idx = expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    paid = ended = 0
+    for t in range(100):
+        actions = rng.choice(7, size=(e, agents), p=[0.14, 0.14, 0.3, 0.02, 0.02, 0.38, 0.0]).astype(np.uint8)
+        order = np.argsort(rng.random((e, agents)), axis=1).astype(np.uint8)
+        out = env.step(actions, order)
+        img, direction, rew, term, trunc = ora.step(actions, order)
+        img, direction = img.copy(), direction.copy()
+        paid += int((rew > 0).any(axis=1).sum())
+        ended += int((term.all(axis=1) & ~trunc.all(axis=1)).sum())
+        done = term.all(axis=1) | trunc.all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            if mode == 0:
+                compare(out, (img, direction, rew, term, trunc), f"{rooms} rooms step {t}")
+                new = rng.integers(0, n_l, size=e)
+                ora.load(ids, pool[0][new[ids]], pool[1][new[ids]], pool[2][new[ids]])
+                env.reset(layout_idx=new, mask=done.astype(np.uint8))
+                continue
+            episode[ids] += 1
+            idx = expected_layout(ids, episode[ids], n_l)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+            img[ids] = ora.gen_obs()[ids]
+            direction[ids] = ora.agents[ids, :, 2]
+        compare(out, (img, direction, rew, term, trunc), f"{rooms} rooms mode {mode} step {t}")
+        if t % 10 == 9:
+            compare_state(env, ora, f"{rooms} rooms mode {mode} step {t}")  # (meta[0..1]: the doors paid so far)
+    compare_state(env, ora, f"{rooms} rooms mode {mode}")
+    assert paid > 200 and (ended > 0 or rooms > 8), (paid, ended)  # (the ending needs 4 to 6 doors within 45 steps)
+    env.close()
+
+
 def fmix32(h):
     h = h ^ (h >> np.uint32(16))
     h = h * np.uint32(0x85EBCA6B)

@@ -20,6 +20,7 @@ FAMILIES = {
     "lockedhallway4": ("MultiGrid-LockedHallway-4Rooms-v0", 4, {}),
     "lockedhallway6": ("MultiGrid-LockedHallway-6Rooms-v0", 3, dict(max_hallway_keys=2)),
     "lockedhallway2_room7": ("MultiGrid-LockedHallway-2Rooms-v0", 3, dict(room_size=7, max_keys_per_room=1)),
+    "lockedhallway8_room4": ("MultiGrid-LockedHallway-6Rooms-v0", 3, dict(num_rooms=8, room_size=4)),
     "blockedunlockpickup_room8": ("MultiGrid-BlockedUnlockPickup-v0", 5, dict(room_size=8)),
     "redbluedoors6": ("MultiGrid-RedBlueDoors-6x6-v0", 4, {}),
 }
@@ -109,7 +110,11 @@ def test_structure_and_determinism(family):
         for i in range(200):
             doors = g[i][g[i, :, :, 0] == DOOR]
             keys = g[i][g[i, :, :, 0] == KEY]
-            assert sorted(doors[:, 1]) == sorted(keys[:, 1]) and len(set(doors[:, 1])) == rooms
+            assert sorted(doors[:, 1]) == sorted(keys[:, 1])
+            if rooms <= 6:
+                assert len(set(doors[:, 1])) == rooms
+            else:  # colours repeat; meta[3] = the number of distinct ones (locked_hallway.py:150-151,160-166)
+                assert len(set(doors[:, 1])) == meta[i, 3] <= 6 and (meta[i, :3] == 0).all()
             assert (doors[:, 2] == LOCKED).all() and (keys[:, 2] == 4).all()
         rs = (w - 1) // 3 + 1
         assert ((a[:, :, 0] > rs - 1) & (a[:, :, 0] < 2 * (rs - 1))).all()  # agents start in the hallway
@@ -169,7 +174,7 @@ def test_distribution_matches_host_generators(family):
     assert chi2_same(checks["agent0 cell"]["dev"], shifted, w * h) < 1e-6
 
 
-@pytest.mark.parametrize("family", ["redbluedoors", "blockedunlockpickup", "lockedhallway4"])
+@pytest.mark.parametrize("family", ["redbluedoors", "blockedunlockpickup", "lockedhallway4", "lockedhallway8_room4"])
 def test_stepping_from_device_layouts(family):
     """Header blocks written by the generator (front cells, door positions) are what the step kernel expects."""
     from oracle.coracle import BatchOracle

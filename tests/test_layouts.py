@@ -33,6 +33,27 @@ def test_layout_generator_matches_reference(name):
         assert grid.shape == (spec["width"], spec["height"], 3)
 
 
+def test_lockedhallway_with_more_rooms_than_colours():
+    """Eight rooms: door colours repeat (locked_hallway.py:150-151).  The start states of the `solve_lockedhallway8`
+    trajectories are untouched `reset()` layouts of the reference (RandomMixin seeded 55 * 1000 + n, reset(seed=55 * 7919
+    + n), tests/golden/make_golden.py); meta[3] is len(env.rooms), the number of distinct door colours."""
+    from golden_util import load_group
+    ref_spec, d = load_group("solve_lockedhallway8")
+    spec, gen = envs.make_spec("MultiGrid-LockedHallway-6Rooms-v0", num_agents=2, num_rooms=8, room_size=4,
+                               max_steps=2000, agent_view_size=7)
+    for dct in (spec, ref_spec):
+        dct.pop("mission")
+        dct.pop("training_scheme", None)
+    assert spec == ref_spec and spec["num_rooms"] == 8 and (spec["width"], spec["height"]) == (10, 13)
+    for n in range(len(d["length"])):
+        grid, agents, meta, _ = gen(mixin_rng=np.random.default_rng(55 * 1000 + n), env_rng=np.random.default_rng(55 * 7919 + n))
+        np.testing.assert_array_equal(grid, d["layout_grid"][n])
+        np.testing.assert_array_equal(agents, d["layout_agents"][n])
+        np.testing.assert_array_equal(meta, d["layout_meta"][n])
+        doors = grid[..., 0] == 4
+        assert doors.sum() == 8 and len(set(grid[..., 1][doors].tolist())) == meta[3] < 8
+
+
 @pytest.mark.parametrize("group,name,agents,kw", [
     ("cfg1_empty8", "MultiGrid-Empty-8x8-v0", 2, {}),
     ("cfg2_redbluedoors8", "MultiGrid-RedBlueDoors-8x8-v0", 2, {}),
