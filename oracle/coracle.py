@@ -38,7 +38,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()  # (compiles only when the library is missing or older than its source)
+        try:
+            build()  # (compiles only when the library is missing or older than its source)
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(LIB_PATH):  # (no compiler here: the library that travelled with the tree is used)
+                raise
         _lib = ctypes.CDLL(LIB_PATH)
         p = ctypes.c_void_p
         _lib.mgo_gen_obs.argtypes = [ctypes.POINTER(CSpec), ctypes.c_int64, p, p, p]
