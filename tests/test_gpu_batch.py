@@ -29,6 +29,8 @@ CASES = {
     "crowd8_rbd": ("MultiGrid-RedBlueDoors-6x6-v0", 8, dict(max_steps=40, allow_agent_overlap=False)),
     "crowd8_bup": ("MultiGrid-BlockedUnlockPickup-v0", 8, dict(max_steps=60, joint_reward=True)),
     "crowd6_lh": ("MultiGrid-LockedHallway-2Rooms-v0", 6, dict(max_steps=40)),
+    # more rooms than door colours: doors of one colour are separate doors (locked_hallway.py:150-151)
+    "lh8": ("MultiGrid-LockedHallway-6Rooms-v0", 5, dict(num_rooms=8, room_size=5, max_steps=60)),
     "crowd16_lh": ("MultiGrid-LockedHallway-4Rooms-v0", 16, dict(max_steps=40, allow_agent_overlap=False)),
     # hook-free environments finished inside the lane-per-agent pass: joint rewards, per-agent and joint termination
     "joint8_empty": ("MultiGrid-Empty-5x5-v0", 8, dict(max_steps=30, joint_reward=True, success_termination_mode="all")),

@@ -16,6 +16,8 @@ CASES = [
     ("cfg5_empty16", "MultiGrid-Empty-16x16-v0", 8, 17, {}),
     # constructed with the reference's own defaults: 5 x 5 views (multigrid/base.py:96)
     ("default_empty8", "MultiGrid-Empty-8x8-v0", 2, 21, {"agent_view_size": None}),
+    # eight rooms: more rooms than door colours (locked_hallway.py:150-151), played by the recording's planner
+    ("solve_lockedhallway8", "MultiGrid-LockedHallway-6Rooms-v0", 2, 55, {"num_rooms": 8, "room_size": 4, "max_steps": 2000}),
 ]
 
 
@@ -44,7 +46,7 @@ def test_drop_in_env_matches_reference_from_seed(group, name, agents, seed0, kw,
         np.testing.assert_array_equal(np.stack([obs[i]["image"] for i in range(agents)]), d["reset_image"][n])
         np.testing.assert_array_equal(env.grid_state, d["layout_grid"][n])
         wrapped = RLlibWrapper(env)
-        for t in range(min(60, int(d["length"][n]))):
+        for t in range(min(500 if group.startswith("solve") else 60, int(d["length"][n]))):  # (doors open late)
             acts = {i: int(d["actions"][n, t, i]) for i in range(agents)}
             o, r, term, trunc, info = wrapped.step(acts)
             np.testing.assert_array_equal(np.stack([o[i]["image"] for i in range(agents)]), d["image"][n, t],

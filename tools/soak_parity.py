@@ -8,7 +8,7 @@ import numpy as np
 import test_gpu_batch as tb
 
 SHARDS = int(os.environ.get("SOAK_SHARDS", "1"))
-CASES = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_nooverlap", "crowd8_bup", "crowd6_lh", "crowd8_rbd", "odd3", "odd5", "single"]
+CASES = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_nooverlap", "crowd8_bup", "crowd6_lh", "crowd8_rbd", "odd3", "odd5", "single", "lh8"]
 MIXES = [None, [1, 1, 3, 2, 2, 3, 1], [1, 1, 2, 4, 1, 4, 0]]  # weights over left right forward pickup drop toggle done
 
 
