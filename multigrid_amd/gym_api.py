@@ -132,6 +132,7 @@ class MultiGridEnv:
         self._np_random = layout_rng if layout_rng is not None else np.random.default_rng()
         self._layout_rng = self._np_random
         self.mission = Mission(self.spec["mission"])
+        self.agent_mission = self.mission
         self.step_count = 0
         self._rows = np.zeros((self.num_agents, 8), dtype=np.uint8)
         self.agent_names = []
@@ -171,10 +172,25 @@ class MultiGridEnv:
             self._np_random = np.random.default_rng(seed)
         grid, agents, meta, mission = self._gen(mixin_rng=self._layout_rng, env_rng=self._np_random)
         self.mission = Mission(mission)
+        self.agent_mission = self._sample_agent_mission(seed)
         self._sim.upload_layouts(grid[None], agents[None], meta[None])
         self._sim.reset(layout_idx=self._layout0)
         self.step_count = 0
         return self._obs_dict(self._fetch()), defaultdict(dict)
+
+    def _sample_agent_mission(self, seed: Optional[int]) -> Mission:
+        """The mission the observations carry: ``reset`` seeds the mission space with the reset seed, draws one sample
+        and hands it to every agent (multigrid/base.py:329-332).  A mission space of one text gives that text.
+        BlockedUnlockPickup's space is colours x (box, key) (blockedunlockpickup.py:117-120), so its agents are told to
+        pick up a RANDOM coloured box or key, whatever the environment's own ``mission`` (set afterwards by
+        ``_gen_grid``, :158) says.  Parity unpinned: the draw is gymnasium's ``MultiDiscrete.sample``, which is not
+        importable here; restated from its published source - ``(np_random.random(nvec.shape) * nvec).astype(dtype)``
+        on the generator ``Space.seed(seed)`` makes, ``Generator(PCG64(SeedSequence(seed)))``."""
+        if self.spec["kind"] != _lib.KIND_BLOCKEDUNLOCKPICKUP:
+            return self.mission
+        rng = np.random.default_rng(seed)  # (seed None: fresh entropy, as Space.seed(None))
+        idx = (rng.random(2) * np.array([len(COLOR_NAMES), 2])).astype(np.int64)
+        return Mission(f"pick up the {COLOR_NAMES[idx[0]]} {('box', 'key')[idx[1]]}")
 
     def step(self, actions: Dict[int, int]):
         """multigrid/base.py:364-408 plus the environment's own step hook."""
@@ -241,7 +257,7 @@ class MultiGridEnv:
 
     def _obs_dict(self, got):
         img, direction = got["image"], got["direction"]
-        return {i: {"image": img[i], "direction": direction[i], "mission": self.mission}
+        return {i: {"image": img[i], "direction": direction[i], "mission": self.agent_mission}
                 for i in range(self.num_agents)}
 
     @property

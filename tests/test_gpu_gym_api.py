@@ -135,3 +135,31 @@ def test_competitive_env_ctce_team_outputs():
             assert [trunc[tm] for tm in teams] == list(d["truncated"][n, t]), where
         np.testing.assert_array_equal(env.grid_state, d["post_grid"][n, int(d["length"][n]) - 1])
         env.close()
+
+
+def test_blockedunlockpickup_agents_get_a_sampled_mission():
+    """multigrid/base.py:329-332: ``reset`` seeds the mission space with the reset seed and gives every agent ONE sample
+    of it; BlockedUnlockPickup's space is colours x (box, key), so the observations' mission is a random one while
+    ``env.mission`` names the box that was placed.  (Parity unpinned: gymnasium's sampler is not importable here.)"""
+    from multigrid_amd.constants import COLOR_NAMES
+    from multigrid_amd.gym_api import MultiGridEnv
+    env = MultiGridEnv("MultiGrid-BlockedUnlockPickup-v0", agents=2, layout_rng=np.random.default_rng(1))
+    space = {f"pick up the {c} {t}" for c in COLOR_NAMES for t in ("box", "key")}
+    seen = set()
+    for seed in range(40):
+        obs, _ = env.reset(seed=seed)
+        first = obs[0]["mission"].string
+        assert first in space and obs[1]["mission"] is obs[0]["mission"]
+        assert env.mission.string.endswith(" box") and env.mission.string in space
+        rng = np.random.default_rng(seed)
+        idx = (rng.random(2) * np.array([6, 2])).astype(np.int64)
+        assert first == f"pick up the {COLOR_NAMES[idx[0]]} {('box', 'key')[idx[1]]}"
+        o, *_ = env.step({0: 0, 1: 1})
+        assert o[0]["mission"].string == first  # kept for the episode
+        seen.add(first)
+    assert len(seen) >= 8
+    env.close()
+    other = MultiGridEnv("MultiGrid-Empty-8x8-v0", agents=2)
+    obs, _ = other.reset(seed=3)
+    assert obs[0]["mission"] is other.mission and other.mission.string == "get to the green goal square"
+    other.close()
