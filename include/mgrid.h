@@ -55,8 +55,9 @@ extern "C" {
                                          (:498-523), pickup rewards and penalty (:425-472); at most 8 agents; agents
                                          act in `order_dev` order = the order of the caller's actions dict (:633-641),
                                          index order when order_dev is NULL; the step's info dict comes back through
-                                         MgOut.info_dev.  Not reproduced: policy objects (`policies_map`) and the
-                                         mission texts. */
+                                         MgOut.info_dev, which also says whose pickup was a rewarded key or ball
+                                         pickup (what the mission texts are rewritten from, :438-468).  Not
+                                         reproduced: policy objects (`policies_map`). */
 
 /* what happens to an environment whose episode ended in this step */
 #define MG_AUTORESET_NONE 0      /* nothing: the caller resets with mg_reset (reference behaviour) */
@@ -123,9 +124,12 @@ typedef struct MgOut {
                                 Written by steps only. */
     uint8_t *info_dev;       /* [E][A] MG_KIND_COMPETITIVE steps only: the info dict of the step per agent
                                 (competative_red_blue_door.py:380-388), packed: bit 0 door_open_done (:490-492), bit 1
-                                got_eliminated_done (:502), bit 2 eliminated_opponents_done and bits 4-7
-                                eliminated_opponent_num (:517-522).  Under "CTCE" the reference keys the dict by team
-                                (:320-328): or the flags and sum the counts over a team's agents.  Not touched for the
+                                got_eliminated_done (:502), bit 2 eliminated_opponents_done and bits 4-5
+                                eliminated_opponent_num (:517-522; at most one per agent and step).  Under "CTCE" the
+                                reference keys the dict by team (:320-328): or the flags and sum the counts over a
+                                team's agents.  Bit 6 / bit 7: the agent's pickup in this step was a rewarded key /
+                                ball pickup (:428-436 / :445-454), after which the reference rewrites the mission
+                                texts of the agent and its team mates (:438-443 / :456-468).  Not touched for the
                                 other kinds (their info dicts are empty, base.py:408). */
 } MgOut;
 

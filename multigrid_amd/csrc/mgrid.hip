@@ -555,7 +555,9 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
         }
         uint64_t iterm = termw;  // agent.terminated
         // the step's info dict (:320-328, :380-388), a byte per agent: bit 0 door_open_done, bit 1 got_eliminated_done,
-        // bit 2 eliminated_opponents_done, bits 4-7 eliminated_opponent_num
+        // bit 2 eliminated_opponents_done, bits 4-5 eliminated_opponent_num (at most one per step: the elimination that
+        // leaves no opponent); bits 6 / 7: the agent's pickup was a rewarded key / ball pickup, after which the reference
+        // rewrites the team's mission texts (:438-443, :456-468)
         uint64_t infow = 0;
         if (p.per_agent() && termw != 0 && termw != ones) toutw = 0;  // :375-378: some but not all -> nobody
         uint32_t ball_n = h0.w & 0xFFFF;  // meta[0], meta[1]
@@ -650,6 +652,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                 if (ct == T_KEY && cs == S_AVAILABLE && cc == my_color) {  // :428-436
                     if (rb) flags |= FLAG_KEY_USED << (cc >> 1);
                     racc[i] += p.schemes[4 * i + RS_KEY];
+                    infow |= 0x40ull << (8 * i);  // the key pickup that rewrites the team's missions, :438-443
                 } else if (ct == T_BALL && rb && cc != my_color && fxy == init_xy) {  // :445-454
                     const int sh = 8 * (cc >> 1), cnt = (ball_n >> sh) & 0xFF;
                     double d = 0.9;  // Ball.__new__ default, world_object.py:583
@@ -657,6 +660,7 @@ __device__ void act_env_small(const KParams &p, uint8_t *lds, int slot, int env,
                     for (int j = 0; j < cnt; ++j) d *= d;
                     racc[i] += p.schemes[4 * i + RS_BALL] * d;
                     if (cnt < 255) ball_n += 1u << sh;
+                    infow |= 0x80ull << (8 * i);  // the ball pickup that rewrites the team's missions, :456-468
                 } else {
                     racc[i] -= p.schemes[4 * i + RS_INVALID];  // :470-472
                 }

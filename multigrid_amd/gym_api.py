@@ -276,15 +276,41 @@ class MultiGridEnv:
         return self._sim.get_state()["grid"][0].cpu().numpy().astype(np.int64)
 
 
+# the texts of CompetativeRedBlueDoorEnvV3's mission space, in its order (competative_red_blue_door.py:158-168)
+COMPETITIVE_MISSIONS = ("Go pick up the key or the ball for opening the door", "Go pick up the key",
+                        "Go move away the ball", "Go open the door with the key")
+
+
+def competitive_missions_after_step(missions, info, order, rows):
+    """The agents' mission texts (indices into ``COMPETITIVE_MISSIONS``) after a step's handlers have run
+    (``_default_extra_action_handle_steps``, competative_red_blue_door.py:438-468; the observations of the NEXT step
+    carry them).  ``info``: the step's info bytes, bit 6 / 7 = the agent's pickup was a rewarded key / ball pickup;
+    ``order``: the order in which the agents were handled; ``rows``: the agent rows the step left."""
+    missions = list(missions)
+    key_type = 5  # Type.key
+    for i in order:
+        mates = [k for k in range(len(missions)) if k != i and rows[k][7] == rows[i][7]]
+        if info[i] & 0x40:  # :438-443
+            missions[i] = 3
+            for k in mates:
+                missions[k] = 2
+        elif info[i] & 0x80:  # :456-468
+            missions[i] = 2
+            for k in mates:
+                missions[k] = 3 if rows[k][4] == key_type and rows[k][5] == rows[k][7] else 1
+    return missions
+
+
 class CompetativeRedBlueDoorEnv(MultiGridEnv):
     """Drop-in for ``CompetativeRedBlueDoorEnvV3`` with its default step handlers (no policy objects):
     multigrid/envs/competative_red_blue_door.py:24.  With ``training_scheme`` "DTDE" / "CTDE" everything is keyed by
     agent name (``"red_0"``), actions ``{name: action}`` (:372-423); with "CTCE" by team, actions
     ``{team: [action of each team member]}``, observations ``{team: [{"agent_id", "image", "direction", "mission"}]}``,
     rewards summed and flags and-ed per team (:319-370).  Agents act in the order of the keys of the actions dict
-    (:624-643).  The step's info dict (:320-328, :380-388) is rebuilt from the bytes the launch returns.  The mission
-    texts the reference rewrites on pickups are not reproduced (the mission stays the first of the mission space's
-    texts)."""
+    (:624-643).  The step's info dict (:320-328, :380-388) is rebuilt from the bytes the launch returns, and so are the
+    mission texts the reference rewrites after rewarded key and ball pickups (:438-468).  The text the agents start an
+    episode with is a sample of the mission space (multigrid/base.py:329-332), drawn as ``_sample_agent_mission``
+    says (parity unpinned there)."""
 
     INFO_KEYS = ("door_open_done", "got_eliminated_done", "eliminated_opponents_done", "eliminated_opponent_num")
 
@@ -304,12 +330,25 @@ class CompetativeRedBlueDoorEnv(MultiGridEnv):
         for i, n in enumerate(self.agent_names):
             self.team_members.setdefault(n.rsplit("_", 1)[0], []).append(i)
         self.teams = {t: len(m) for t, m in self.team_members.items()}
+        self._missions = [0] * self.num_agents  # indices into COMPETITIVE_MISSIONS; drawn at reset
 
     def _format_obs(self, obs):
         if self.training_scheme == "CTCE":  # gen_obs, :298-309
             return {team: [dict(obs[k], agent_id=j) for j, k in enumerate(members)]
                     for team, members in self.team_members.items()}
         return {self.agent_names[k]: obs[k] for k in range(self.num_agents)}  # :310-316
+
+    def _sample_agent_mission(self, seed: Optional[int]) -> Mission:
+        rng = np.random.default_rng(seed)  # MissionSpace.seed(seed), then one sample for every agent (base.py:329-332)
+        first = int((rng.random(1) * np.array([len(COMPETITIVE_MISSIONS)])).astype(np.int64)[0])
+        self._missions = [first] * self.spec["num_agents"]
+        return Mission(COMPETITIVE_MISSIONS[first])
+
+    def _obs_dict(self, got):
+        obs = super()._obs_dict(got)
+        for k, text in enumerate(self._missions):
+            obs[k]["mission"] = Mission(COMPETITIVE_MISSIONS[text])
+        return obs
 
     def reset(self, seed: Optional[int] = None, **kwargs):
         obs, infos = super().reset(seed=seed, **kwargs)
@@ -338,18 +377,20 @@ class CompetativeRedBlueDoorEnv(MultiGridEnv):
         rew = got["reward"]  # doubles, accumulated on the device as the reference accumulates them
         term, trunc = got["terminated"].astype(bool), got["truncated"].astype(bool)
         obs = self._format_obs(self._obs_dict(got))
-        bits = got["info"]  # per agent: flags in bits 0-2, eliminated_opponent_num in bits 4-7
+        bits = got["info"]  # per agent: flags in bits 0-2, eliminated_opponent_num in bits 4-5, pickup events in 6-7
+        # (the observations above carry the texts as they were before this step's handlers ran, :307,315)
+        self._missions = competitive_missions_after_step(self._missions, bits, order, self._rows)
         if self.training_scheme == "CTCE":  # :346-368; the info entries are the teams' (:320-328)
             rewards = {t: float(sum(rew[k] for k in m)) for t, m in self.team_members.items()}
             terminations = {t: bool(all(term[k] for k in m)) for t, m in self.team_members.items()}
             truncations = {t: bool(all(trunc[k] for k in m)) for t, m in self.team_members.items()}
-            info = {t: self._info_entry(int(np.bitwise_or.reduce(bits[m]) & 7), int((bits[m] >> 4).sum()))
+            info = {t: self._info_entry(int(np.bitwise_or.reduce(bits[m]) & 7), int(((bits[m] >> 4) & 3).sum()))
                     for t, m in self.team_members.items()}
         else:  # :408-421
             rewards = {n: float(rew[k]) for k, n in enumerate(self.agent_names)}
             terminations = {n: bool(term[k]) for k, n in enumerate(self.agent_names)}
             truncations = {n: bool(trunc[k]) for k, n in enumerate(self.agent_names)}
-            info = {n: self._info_entry(int(bits[k]) & 7, int(bits[k]) >> 4) for k, n in enumerate(self.agent_names)}
+            info = {n: self._info_entry(int(bits[k]) & 7, (int(bits[k]) >> 4) & 3) for k, n in enumerate(self.agent_names)}
         return obs, rewards, terminations, truncations, info
 
 

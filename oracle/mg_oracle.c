@@ -147,7 +147,8 @@ typedef struct {
     uint8_t flags;
     double *reward;
     uint8_t *info; /* CompetativeRedBlueDoor: per agent, bit 0 door_open_done, bit 1 got_eliminated_done, bit 2
-                      eliminated_opponents_done, bits 4-7 eliminated_opponent_num (:320-328, :380-388); may be NULL */
+                      eliminated_opponents_done, bits 4-5 eliminated_opponent_num (:320-328, :380-388), bit 6 / 7 the
+                      agent's pickup was a rewarded key / ball pickup (:428-468); may be NULL */
 } env_t;
 
 static uint8_t *cell(env_t *e, int x, int y) { return e->grid + ((size_t)x * e->sp->height + y) * 3; }
@@ -289,6 +290,7 @@ static void comp_pickup_rewards(env_t *e, int i, int act) {
     if (ag[ACT] == T_KEY && carried_state(e, i) == S_AVAILABLE && ag[ACC] == ag[ACOLOR]) { /* :428-436 */
         if (ag[ACC] == C_RED || ag[ACC] == C_BLUE) e->flags |= (uint8_t)(1u << (ag[ACC] / 2));
         e->reward[i] += rs[RS_KEY];
+        if (e->info) e->info[i] |= 0x40; /* the pickup that rewrites the team's missions, :438-443 */
         return;
     }
     if (ag[ACT] == T_BALL && ag[ACC] != ag[ACOLOR] && (ag[ACC] == C_RED || ag[ACC] == C_BLUE)) { /* :445-454 */
@@ -302,6 +304,7 @@ static void comp_pickup_rewards(env_t *e, int i, int act) {
             for (int n = 0; n < e->meta[slot]; ++n) d *= d;
             e->reward[i] += rs[RS_BALL] * d;
             if (e->meta[slot] < 255) e->meta[slot]++;
+            if (e->info) e->info[i] |= 0x80; /* the pickup that rewrites the team's missions, :456-468 */
             return;
         }
     }

@@ -310,6 +310,9 @@ class Env:
         self.unlocked_mask = 0
         self.unlocked_at = set()
         self.door_colours = 0
+        self.missions = [""] * spec.num_agents  # CompetativeRedBlueDoor: the agents' mission texts (set by the caller at reset)
+        self.obs_missions = list(self.missions)
+        self.pickup_events = {}
         # RedBlueDoors: the blue Door OBJECT was re-closed after a failure while
         # its grid cell still reads open (redbluedoors.py:185 has no grid.update)
         self.blue_stale_open = False
@@ -591,6 +594,12 @@ class Env:
             if ag[i, CC] in (RED, BLUE):
                 self.flags |= FLAG_KEY_USED[ag[i, CC] // 2]
             rewards[i] += rs[RS_KEY]
+            self.pickup_events[i] = 1
+            # "mimic communications", :438-443 (`training_scheme == "DTDE" or "CTDE"` is always true)
+            self.missions[i] = "Go open the door with the key"
+            for k in range(sp.num_agents):
+                if ag[k, COLOR] == ag[i, COLOR] and k != i:
+                    self.missions[k] = "Go move away the ball"
             return
         if ag[i, CT] == BALL and ag[i, CC] != ag[i, COLOR] and ag[i, CC] in (RED, BLUE):  # :445-454
             # Ball(color="blue", init_pos=next to the red door), Ball(color="red", init_pos=next to the blue door) :230-232
@@ -602,6 +611,12 @@ class Env:
                     d *= d
                 rewards[i] += rs[RS_BALL] * d
                 self.meta[slot] += 1  # discount_factor *= discount_factor
+                self.pickup_events[i] = 2
+                self.missions[i] = "Go move away the ball"  # :456-468
+                for k in range(sp.num_agents):
+                    if ag[k, COLOR] == ag[i, COLOR] and k != i:
+                        own_key = ag[k, CT] == KEY and ag[k, CC] == ag[k, COLOR]
+                        self.missions[k] = "Go open the door with the key" if own_key else "Go pick up the key"
                 return
         rewards[i] -= rs[RS_INVALID]  # :470-472
 
@@ -612,6 +627,8 @@ class Env:
         self.step_count += 1
         rewards = self.handle_actions(actions, order)
         obs = self.gen_obs()
+        self.obs_missions = list(self.missions)  # the texts this step's observations carry (:307,315); the handlers
+        self.pickup_events = {i: 0 for i in range(sp.num_agents)}  # below rewrite them for the next (1 key, 2 ball pickup)
         terminations = {i: bool(self.agents[i, TERM]) for i in range(sp.num_agents)}
         truncated = self.step_count >= sp.max_steps
         truncations = {i: truncated for i in range(sp.num_agents)}

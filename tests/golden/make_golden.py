@@ -527,8 +527,9 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
             layout_grid=env.grid.state.astype(np.uint8).copy(), layout_agents=agent_rows(env),
             layout_meta=np.zeros(4, np.uint8),
             reset_image=np.stack([o["image"] for o in obs]).astype(np.uint8),
+            reset_mission=np.array([mission_index(o["mission"]) for o in obs], np.uint8),
             actions=[], order=[], image=[], direction=[], reward=[], terminated=[], truncated=[], post_grid=[],
-            post_agents=[], post_flags=[], post_meta=[], info=[])
+            post_agents=[], post_flags=[], post_meta=[], info=[], mission=[])
         after = 0
         for t in range(t_max):
             if script is not None and t < len(script(n)):
@@ -553,6 +554,8 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
             assert img.min() >= 0 and img.max() < 256 and img.shape == (a, v, v, 3)
             tr["image"].append(img.astype(np.uint8))
             tr["direction"].append(np.array([int(x["direction"]) for x in o], np.uint8))
+            # the mission texts the observations carry (:307, :315; rewritten on pickups, :438-468), by MISSION_TEXTS index
+            tr["mission"].append(np.array([mission_index(x["mission"]) for x in o], np.uint8))
             tr["reward"].append(np.array([float(r[nm]) for nm in out_keys], np.float64))
             tr["terminated"].append(np.array([bool(term[nm]) for nm in out_keys]))
             tr["truncated"].append(np.array([bool(trunc[nm]) for nm in out_keys]))
@@ -573,10 +576,10 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
     lens = np.array([len(t["actions"]) for t in trajs], np.int32)
     tm = int(lens.max())
     out = dict(spec=np.array(json.dumps(spec)), length=lens)
-    for key in ("layout_grid", "layout_agents", "layout_meta", "reset_image"):
+    for key in ("layout_grid", "layout_agents", "layout_meta", "reset_image", "reset_mission"):
         out[key] = np.stack([t[key] for t in trajs])
     for key in ("actions", "order", "image", "direction", "reward", "terminated", "truncated", "post_grid",
-                "post_agents", "post_flags", "post_meta", "info"):
+                "post_agents", "post_flags", "post_meta", "info", "mission"):
         first = np.asarray(trajs[0][key][0])
         arr = np.zeros((n, tm) + first.shape, dtype=first.dtype)
         for i, t in enumerate(trajs):
@@ -584,12 +587,21 @@ def record_competitive(name, kw, n_traj, t_max, seed0, edit=None, action_p=None,
         out[key] = arr
     path = os.path.join(HERE, f"{name}.npz")
     np.savez_compressed(path, **out)
-    print(f"info events {out['info'].reshape(-1, 4).sum(axis=0).tolist()}", end="  ")
+    print(f"info events {out['info'].reshape(-1, 4).sum(axis=0).tolist()} missions {np.bincount(out['mission'].ravel(), minlength=4).tolist()}", end="  ")
     print(f"{name:28s} traj={n:3d} steps={int(lens.sum()):6d} nonzero_rewards={int((out['reward'] != 0).sum()):5d} "
           f"positive={int((out['reward'] > 0).sum()):4d} below_minus_half={int((out['reward'] < -0.5).sum()):3d} "
           f"traj_with_termination={int(out['terminated'].any(axis=(1, 2)).sum()):3d} "
           f"flags_seen={sorted(set(out['post_flags'].ravel().tolist()))} ball_max={int(out['post_meta'].max())} "
           f"size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# the texts of the environment's mission space (:158-168), in its order; every text an observation carries is one of them
+MISSION_TEXTS = ("Go pick up the key or the ball for opening the door", "Go pick up the key", "Go move away the ball",
+                 "Go open the door with the key")
+
+
+def mission_index(m) -> int:
+    return MISSION_TEXTS.index(m if isinstance(m, str) else m.string)
 
 
 def comp_free_cells(env):

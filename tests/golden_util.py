@@ -41,10 +41,18 @@ INFO_KEYS = ("door_open_done", "got_eliminated_done", "eliminated_opponents_done
 
 def pack_info(rows):
     """The recorded info entries ``[..., 4]`` (the reference's info dict of a CompetativeRedBlueDoor step, in the order of
-    INFO_KEYS) as the bytes the library and the C oracle return: bit 0 door_open_done, bit 1 got_eliminated_done,
-    bit 2 eliminated_opponents_done, bits 4-7 eliminated_opponent_num."""
+    INFO_KEYS) as the low six bits of the bytes the library and the C oracle return: bit 0 door_open_done, bit 1
+    got_eliminated_done, bit 2 eliminated_opponents_done, bits 4-5 eliminated_opponent_num.  (Bits 6 / 7 of those bytes
+    say that the agent's pickup was a rewarded key / ball pickup - INFO_MASK leaves them out; the mission texts recorded
+    in the fixtures pin them.)"""
     rows = np.asarray(rows).astype(np.uint8)
     return ((rows[..., 0] != 0) | ((rows[..., 1] != 0) << 1) | ((rows[..., 2] != 0) << 2) | (rows[..., 3] << 4)).astype(np.uint8)
+
+
+INFO_MASK = 0x3F
+# the texts the `mission` / `reset_mission` arrays of the competitive fixtures index (tests/golden/make_golden.py)
+MISSION_TEXTS = ("Go pick up the key or the ball for opening the door", "Go pick up the key", "Go move away the ball",
+                 "Go open the door with the key")
 
 
 def pack_info_dict(info, keys):
@@ -61,6 +69,6 @@ def team_info(members, packed):
         count = 0
         for k in team:
             flags |= int(packed[k]) & 7
-            count += int(packed[k]) >> 4
+            count += (int(packed[k]) >> 4) & 3
         out.append(flags | (count << 4))
     return np.asarray(out, np.uint8)

@@ -3,7 +3,7 @@ layouts come from the host generators, agent orders from np_random, exactly as i
 import numpy as np
 import pytest
 
-from golden_util import INFO_KEYS, load_group, pack_info, pack_info_dict
+from golden_util import INFO_KEYS, MISSION_TEXTS, load_group, pack_info, pack_info_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -82,6 +82,8 @@ def test_competitive_env_from_seed_dtde():
         assert isinstance(env, CompetativeRedBlueDoorEnv) and env.agent_names == names and env.teams == {"blue": 1, "red": 1}
         obs, infos = env.reset(seed=61 * 7919 + n)
         assert list(obs) == names and obs[names[0]]["image"].shape == (5, 5, 3)
+        # (the first text is a sample of the mission space drawn with the reset seed: parity unpinned, see gym_api)
+        assert [obs[k]["mission"].string for k in names] == [MISSION_TEXTS[j] for j in d["reset_mission"][n]]
         np.testing.assert_array_equal(np.stack([obs[k]["image"] for k in names]), d["reset_image"][n])
         np.testing.assert_array_equal(env.grid_state, d["layout_grid"][n])
         for t in range(min(150, int(d["length"][n]))):
@@ -93,6 +95,8 @@ def test_competitive_env_from_seed_dtde():
             np.testing.assert_allclose([r[k] for k in names], d["reward"][n, t], atol=1e-6, rtol=0, err_msg=where)
             assert [term[k] for k in names] == list(d["terminated"][n, t]), where
             assert [trunc[k] for k in names] == list(d["truncated"][n, t]), where
+            # the mission texts, rewritten after rewarded key and ball pickups (:438-468)
+            assert [o[k]["mission"].string for k in names] == [MISSION_TEXTS[j] for j in d["mission"][n, t]], where
             assert list(info) == names and list(info[names[0]]) == list(INFO_KEYS), where
             np.testing.assert_array_equal(pack_info_dict(info, names), pack_info(d["info"][n, t]), err_msg=where + " info")
         env.close()
@@ -110,6 +114,7 @@ def test_competitive_env_ctce_team_outputs():
         assert [env.team_members[t] for t in teams] == members
         env.reset(seed=n)
         env._sim.set_state(grid=d["layout_grid"][n][None], agents=d["layout_agents"][n][None])  # the harness-edited start
+        env._missions = d["reset_mission"][n].tolist()  # (... and the texts its episode began with)
         obs = env.gen_obs()
         np.testing.assert_array_equal(np.stack([obs[t][j]["image"] for t in teams for j in range(len(members[0]))]),
                                       d["reset_image"][n])
@@ -129,6 +134,7 @@ def test_competitive_env_ctce_team_outputs():
                 for j, k in enumerate(env.team_members[tm]):
                     assert o[tm][j]["agent_id"] == j
                     img[k] = o[tm][j]["image"]
+                    assert o[tm][j]["mission"].string == MISSION_TEXTS[d["mission"][n, t, k]], where
             np.testing.assert_array_equal(img, d["image"][n, t], err_msg=where)
             np.testing.assert_allclose([r[tm] for tm in teams], d["reward"][n, t], atol=2e-6, rtol=0, err_msg=where)
             assert [term[tm] for tm in teams] == list(d["terminated"][n, t]), where

@@ -2,9 +2,12 @@
 import numpy as np
 import pytest
 
-from golden_util import group_names, load_group, pack_info
+from golden_util import INFO_MASK, group_names, load_group, pack_info
 
 pytestmark = pytest.mark.gpu
+
+
+from multigrid_amd.gym_api import competitive_missions_after_step  # noqa: E402
 
 
 def _mk(spec, n, **kw):
@@ -24,6 +27,7 @@ def test_hip_replays_reference(name):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.image.cpu().numpy(), d["reset_image"], err_msg=f"{name} reset obs")
     np.testing.assert_array_equal(out.direction.cpu().numpy(), d["layout_agents"][:, :, 2])
+    missions = d["reset_mission"].tolist() if "mission" in d else None
     for t in range(int(d["length"].max())):
         live = d["length"] > t
         out = env.step(d["actions"][:, t], d["order"][:, t])
@@ -45,5 +49,10 @@ def test_hip_replays_reference(name):
             np.testing.assert_array_equal(st["flags"].cpu().numpy()[live], d["post_flags"][live, t], err_msg=where + " flags")
             np.testing.assert_array_equal(st["meta"].cpu().numpy()[live], d["post_meta"][live, t], err_msg=where + " meta")
         if "info" in d:  # the step's info dict (multigrid/envs/competative_red_blue_door.py:380-388), a byte per agent
-            np.testing.assert_array_equal(out.info.cpu().numpy()[live], pack_info(d["info"][live, t]), err_msg=where + " info")
+            info = out.info.cpu().numpy()
+            np.testing.assert_array_equal(info[live] & INFO_MASK, pack_info(d["info"][live, t]), err_msg=where + " info")
+            # bits 6 / 7 (rewarded key / ball pickups) drive the mission texts the next observations carry (:438-468)
+            np.testing.assert_array_equal(np.asarray(missions)[live], d["mission"][live, t], err_msg=where + " missions")
+            rows = st["agents"].cpu().numpy()
+            missions = [competitive_missions_after_step(missions[k], info[k], d["order"][k, t], rows[k]) for k in range(n)]
     env.close()

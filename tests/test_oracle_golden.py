@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from golden_util import group_names, load_group, pack_info, pack_info_dict, team_info
+from golden_util import INFO_MASK, MISSION_TEXTS as MISSIONS, group_names, load_group, pack_info, pack_info_dict, team_info
+from multigrid_amd.gym_api import competitive_missions_after_step
 from oracle import pyref
 
 
@@ -20,12 +21,16 @@ def test_pyref_replays_reference(name, fast_obs):
         obs = env.load_layout(d["layout_grid"][n], d["layout_agents"][n], d["layout_meta"][n])
         img0 = np.stack([obs[i]["image"] for i in range(a)])
         np.testing.assert_array_equal(img0, d["reset_image"][n], err_msg=f"{name}[{n}] reset obs")
+        if "mission" in d:  # CompetativeRedBlueDoorEnvV3: the texts the agents start with (a sample of the mission space)
+            env.missions = [MISSIONS[k] for k in d["reset_mission"][n]]
         for t in range(int(d["length"][n])):
             acts = d["actions"][n, t]
             o, r, term, trunc, info = env.step({i: int(acts[i]) for i in range(a)}, d["order"][n, t])
             where = f"{name}[{n}] step {t}"
             if "info" in d:  # CompetativeRedBlueDoorEnvV3: the step's info dict
                 np.testing.assert_array_equal(pack_info_dict(info, range(a)), pack_info(d["info"][n, t]), err_msg=where + " info")
+            if "mission" in d:  # ... and the mission texts its observations carry, rewritten after rewarded pickups
+                assert env.obs_missions == [MISSIONS[k] for k in d["mission"][n, t]], where + " missions"
             img = np.stack([o[i]["image"] for i in range(a)])
             np.testing.assert_array_equal(img, d["image"][n, t], err_msg=where + " image")
             np.testing.assert_array_equal([int(o[i]["direction"]) for i in range(a)],
@@ -53,6 +58,7 @@ def test_c_oracle_replays_reference(name):
     bo = BatchOracle(spec, n)
     bo.load(np.arange(n), d["layout_grid"], d["layout_agents"], d["layout_meta"])
     np.testing.assert_array_equal(bo.gen_obs(), d["reset_image"], err_msg=f"{name} reset obs")
+    missions = d["reset_mission"].tolist() if "mission" in d else None
     for t in range(int(d["length"].max())):
         live = d["length"] > t
         img, direction, rew, term, trunc = bo.step(d["actions"][:, t], d["order"][:, t])
@@ -67,7 +73,10 @@ def test_c_oracle_replays_reference(name):
         if "post_flags" in d:
             np.testing.assert_array_equal(bo.flags[live], d["post_flags"][live, t], err_msg=where + " flags")
             np.testing.assert_array_equal(bo.meta[live], d["post_meta"][live, t], err_msg=where + " ball counters")
-            np.testing.assert_array_equal(bo.info[live], pack_info(d["info"][live, t]), err_msg=where + " info")
+            np.testing.assert_array_equal(bo.info[live] & INFO_MASK, pack_info(d["info"][live, t]), err_msg=where + " info")
+            # bits 6 / 7 of the info bytes (rewarded key / ball pickups) drive the mission texts of the next observations
+            np.testing.assert_array_equal(np.asarray(missions)[live], d["mission"][live, t], err_msg=where + " missions")
+            missions = [competitive_missions_after_step(missions[k], bo.info[k], d["order"][k, t], bo.agents[k]) for k in range(n)]
 
 
 def team_outputs(members, reward, terminated, truncated):
@@ -97,7 +106,9 @@ def test_ctce_outputs():
     for k in range(n):
         env = pyref.Env(make_spec(spec))
         env.load_layout(d["layout_grid"][k], d["layout_agents"][k], d["layout_meta"][k])
+        env.missions = [MISSIONS[j] for j in d["reset_mission"][k]]
         envs_py.append(env)
+    missions = d["reset_mission"].tolist()
     for t in range(int(d["length"].max())):
         img, direction, rew, term, trunc = bo.step(d["actions"][:, t], d["order"][:, t])
         for k in range(n):
@@ -108,6 +119,9 @@ def test_ctce_outputs():
             want_info = pack_info(d["info"][k, t])
             np.testing.assert_array_equal(team_info(members, pack_info_dict(info, range(a))), want_info, err_msg=where + " info")
             np.testing.assert_array_equal(team_info(members, bo.info[k]), want_info, err_msg=where + " info (C)")
+            assert envs_py[k].obs_missions == [MISSIONS[j] for j in d["mission"][k, t]], where + " missions"
+            assert list(missions[k]) == d["mission"][k, t].tolist(), where + " missions (C)"
+            missions[k] = competitive_missions_after_step(missions[k], bo.info[k], d["order"][k, t], bo.agents[k])
             for got in (team_outputs(members, r, tm, tr), team_outputs(members, rew[k], term[k], trunc[k])):
                 assert got[0] == list(d["reward"][k, t]), where + " team rewards"
                 assert got[1] == list(d["terminated"][k, t]), where + " team terminations"
