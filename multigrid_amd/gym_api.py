@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ctypes
 from collections import defaultdict
-from typing import Any, Dict, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

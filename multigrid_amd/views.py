@@ -21,7 +21,6 @@ from typing import Dict, Optional
 
 import torch
 
-from . import _lib
 from .batched import BatchedMultiGrid
 
 
