@@ -15,7 +15,9 @@
  *   grid    uint8 [E][W][H][3]   grid.state, x-major      (multigrid/core/grid.py:53)
  *   agents  uint8 [E][A][8]      x y dir terminated carry_type carry_color carry_state color
  *                                                          (multigrid/core/agent.py:266-275)
- *   meta    uint8 [E][4]         RedBlueDoors: red_x red_y blue_x blue_y
+ *   meta    uint8 [E][4]         RedBlueDoors: red_x red_y blue_x blue_y; LockedHallway with more than six
+ *                                rooms: meta[0..1] doors already rewarded (bit 2 * row + side), meta[3] the
+ *                                number of distinct door colours (locked_hallway.py:150-151,160-166,213)
  *   steps   int32 [E]            step_count                (multigrid/base.py:350,395)
  *   flags   uint8 [E]            bits 0-5: LockedHallway doors already rewarded, by door
  *                                colour (locked_hallway.py:190,204-205); bit 7: the blue

@@ -22,7 +22,8 @@ agents  (A, 8) integer array, columns ``X Y DIR TERM CT CC CS COLOR`` - the
         reference's 9-column ``AgentState`` row (multigrid/core/agent.py:266-275)
         without the constant type column and with position first.
 meta    (4,) integers: RedBlueDoors ``(red_x, red_y, blue_x, blue_y)``; unused
-        (zeros) by the other environment kinds.
+        by the other environment kinds (LockedHallway with more than six rooms
+        counts its distinct door colours from the grid itself).
 """
 from __future__ import annotations
 
