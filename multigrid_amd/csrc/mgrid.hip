@@ -1773,12 +1773,52 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             layout = min(max(layout, 0), p.num_layouts - 1);
             lsrc[lane] = layout;
         }
-        uint64_t m = active_mask;
-        while (m) {
-            const int s = __builtin_ctzll(m);
-            m &= m - 1;
-            reload_env(p, lds, s, e0 + s, __shfl(layout, s), __shfl(episode, s), lane, nullptr);
+        wave_sync();
+        // Every 16-byte piece of the tile's header blocks and grids comes from the pool entry of its environment:
+        // the pieces are independent, so four are asked for before the first is stored (a reset of many environments
+        // is a gather, not a chain of restarts).
+        const uint8_t *pool_hdr_ = late_arg<const uint8_t *>(offsetof(KParams, pool_hdr));
+        const uint8_t *pool_grid_ = late_arg<const uint8_t *>(offsetof(KParams, pool_grid));
+        uint4 *dh = reinterpret_cast<uint4 *>(lds + p.o.hdr);
+        uint4 *dg = reinterpret_cast<uint4 *>(late_arg<uint8_t *>(offsetof(KParams, grid)) + static_cast<size_t>(e0) * p.GS);
+        const int per_h = p.HS / 16, hpad = (p.HP - p.HS) >> 4;
+        // (loads never depend on a condition: a piece beyond the end, or of an environment that is not reset, is read
+        // from a valid place and not stored)
+        const int n_h = net * per_h, n_g = net * per;
+        auto hdr_piece = [&](int i, bool &ok, int &at) {
+            const int ic = min(i, n_h - 1), slot = udiv(ic, p.magic_ph);
+            ok = i < n_h && ((active_mask >> slot) & 1);
+            at = ic + hpad * slot;
+            return reinterpret_cast<const uint4 *>(pool_hdr_ + static_cast<size_t>(max(lsrc[slot], 0)) * p.HS)[ic - slot * per_h];
+        };
+        auto grid_piece = [&](int i, bool &ok) {
+            const int ic = min(i, n_g - 1), slot = udiv(ic, p.magic_per);
+            ok = i < n_g && ((active_mask >> slot) & 1);
+            return reinterpret_cast<const uint4 *>(pool_grid_ + static_cast<size_t>(max(lsrc[slot], 0)) * p.GS)[ic - slot * per];
+        };
+#pragma unroll 1
+        for (int i0 = lane; i0 < n_h; i0 += 256) {
+            bool k0, k1, k2, k3;
+            int a0, a1, a2, a3;
+            const uint4 v0 = hdr_piece(i0, k0, a0), v1 = hdr_piece(i0 + 64, k1, a1), v2 = hdr_piece(i0 + 128, k2, a2),
+                        v3 = hdr_piece(i0 + 192, k3, a3);
+            if (k0) dh[a0] = v0;
+            if (k1) dh[a1] = v1;
+            if (k2) dh[a2] = v2;
+            if (k3) dh[a3] = v3;
         }
+#pragma unroll 1
+        for (int i0 = lane; i0 < n_g; i0 += 256) {
+            bool k0, k1, k2, k3;
+            const uint4 v0 = grid_piece(i0, k0), v1 = grid_piece(i0 + 64, k1), v2 = grid_piece(i0 + 128, k2),
+                        v3 = grid_piece(i0 + 192, k3);
+            if (k0) dg[i0] = v0;
+            if (k1) dg[i0 + 64] = v1;
+            if (k2) dg[i0 + 128] = v2;
+            if (k3) dg[i0 + 192] = v3;
+        }
+        wave_sync();
+        if (active) *reinterpret_cast<uint32_t *>(lds + p.o.hdr + lane * p.HP + H_EPISODE) = episode;  // the environment's own counter
         wave_sync();
     }
     if (MODE != MODE_STEP) {
@@ -1923,7 +1963,8 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             const int np = ns * A;
             const uint64_t sub_mask = (active_mask >> s0) & ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
             const bool all_active = sub_mask == ((ns == 64) ? ~0ull : ((1ull << ns) - 1ull));
-            const bool has_next = !MULTI && s0 + NE < net;
+            // (a reset takes every grid it looks at from the layout pool - patch() - and prefetches none from the state)
+            const bool has_next = !MULTI && MODE != MODE_RESET && s0 + NE < net;
             const int gslot0 = MULTI ? s0 : 0;  // where the sub-tile's grids start in LDS
             MG_EXP(
             unsigned long long tk0 = 0, tka = 0, tk1 = 0, tk2 = 0, tk3 = 0;
@@ -1937,10 +1978,7 @@ __attribute__((amdgpu_waves_per_eu(MULTI ? MG_WAVES_MULTI : MG_WAVES_SINGLE, 8))
             MG_EXP(MG_TICK(tka);)
             // the sub-tile's grids: the first ones were set out when the launch began, the others came in at the
             // end of the pass before; what was restarted in this launch is taken from the pool
-            if (!MULTI && s0 == 0 && !(MODE == MODE_STEP && ACT_FIRST)) {
-                if (MODE == MODE_RESET) issue(0);
-                commit(0);
-            }
+            if (!MULTI && s0 == 0 && MODE != MODE_RESET && !(MODE == MODE_STEP && ACT_FIRST)) commit(0);
             if (!MULTI && !(MODE == MODE_STEP && ACT_FIRST && s0 == 0)) patch(s0, gslot0);
             wave_sync();
             if (s0 == 0) MG_STAMP(4);
