@@ -69,3 +69,54 @@ def test_limits_are_reported():
     spec, _ = envs.make_spec("MultiGrid-Empty-8x8-v0", num_agents=65, agent_view_size=7)
     with pytest.raises(MgError, match="num_agents"):
         BatchedMultiGrid(spec, 4, device=0)
+
+
+@pytest.mark.parametrize("view", [9, 11])
+def test_wide_views_through_the_other_entry_points(view):
+    """9 x 9 and 11 x 11 views through the entry points the parity replays do not use: a caller-held state
+    (mg_gen_obs_of_state), two stream shards (mg_step_shards), several steps per call (mg_step_n, queued as single
+    launches for these views) and the one-hot output - each against the C oracle."""
+    import torch
+    from multigrid_amd.batched import BatchedMultiGrid, gen_obs_of_state
+    from multigrid_amd.sharded import StreamShardedMultiGrid
+    from oracle import pyref
+    from oracle.coracle import BatchOracle
+    e, agents = 700, 3
+    spec, gen = envs.make_spec("MultiGrid-LockedHallway-6Rooms-v0", num_agents=agents, num_rooms=8, room_size=4,
+                               max_steps=30, agent_view_size=view)
+    pool = layouts.make_pool(gen, 32, seed0=view)
+    idx = np.arange(e) % 32
+    ora = BatchOracle(spec, e)
+    ora.load(np.arange(e), pool[0][idx], pool[1][idx], pool[2][idx])
+    dev = torch.device("cuda:0")
+    # a state the caller holds
+    img = torch.zeros((e, agents, view, view, 3), dtype=torch.uint8, device=dev)
+    oh = torch.zeros((e, agents, view, view, 24), dtype=torch.uint8, device=dev)
+    gen_obs_of_state(spec, torch.as_tensor(pool[0][idx]).to(dev).contiguous(), torch.as_tensor(pool[1][idx]).to(dev).contiguous(),
+                     image=img, onehot=oh)
+    torch.cuda.synchronize()
+    want = ora.gen_obs()
+    np.testing.assert_array_equal(img.cpu().numpy(), want)
+    np.testing.assert_array_equal(oh.cpu().numpy(), pyref.one_hot_batch(want))
+    # two stream shards, then several steps per call on one handle
+    sh = StreamShardedMultiGrid(spec, e, shards=2, device=0)
+    sh.upload_layouts(pool[0], pool[1], pool[2])
+    sh.reset(layout_idx=idx)
+    one = BatchedMultiGrid(spec, e, device=0)
+    one.upload_layouts(pool[0], pool[1], pool[2])
+    one.reset(layout_idx=idx)
+    rng = np.random.default_rng(view)
+    acts = rng.choice(7, size=(6, e, agents), p=[0.15, 0.15, 0.3, 0.1, 0.05, 0.25, 0.0]).astype(np.uint8)
+    order = np.argsort(rng.random((6, e, agents)), axis=2).astype(np.uint8)
+    outn = one.step_n(acts, order)
+    torch.cuda.synchronize()
+    for t in range(6):
+        out = sh.step(acts[t], order[t])
+        img_t, direction, rew, term, trunc = ora.step(acts[t], order[t])
+        torch.cuda.synchronize()
+        for got in (out.image, outn.image[t]):
+            np.testing.assert_array_equal(got.cpu().numpy(), img_t, err_msg=f"view {view} step {t}")
+        np.testing.assert_allclose(outn.reward[t].cpu().numpy(), rew, rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(out.terminated.cpu().numpy(), term)
+    sh.close()
+    one.close()
