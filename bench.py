@@ -344,6 +344,48 @@ def latency_one_env(args):
                 dict_api_step_us=dict_step * 1e6, dict_api_agent_steps_per_s=agents / dict_step)
 
 
+def other_entry_points(args):
+    """The path's other two launches, `MultiGridEnv.gen_obs` (mg_gen_obs) and `MultiGridEnv.reset` of every environment
+    (mg_reset with a start state picked per environment), on the per-GPU batches of BASELINE configs 3 - 5: launch
+    time by HIP events, bytes per environment (state in, images out; for a reset the pool entry in and the state out
+    as well) and the fraction of the 8 TB/s roofline."""
+    import torch
+
+    from multigrid_amd import envs, layouts
+    from multigrid_amd.batched import BatchedMultiGrid
+
+    dev = torch.device("cuda", local_device_index())
+    out = []
+    for cfg_id in (3, 4, 5):
+        name, agents, num_envs, _, kw = CONFIGS[cfg_id]
+        spec, gen = envs.make_spec(name, num_agents=agents, agent_view_size=7, **kw)
+        env = BatchedMultiGrid(spec, num_envs, device=dev)
+        grids, ags, metas, _ = layouts.make_pool(gen, 256, seed0=0)
+        env.upload_layouts(grids, ags, metas)
+        env.reset()
+        idx = torch.randint(0, 256, (num_envs,), device=dev, dtype=torch.int32)
+        a, v = agents, spec["view_size"]
+        hs = (16 + 8 * (a + a % 2) + 2 * (a + 2) + 15) // 16 * 16  # header block and grid of one environment, as held
+        gs = (2 * spec["width"] * spec["height"] + 15) // 16 * 16   # on the device
+        images = (3 * v * v + 1) * a
+        for entry, fn, nbytes in (("mg_gen_obs", env.gen_obs, hs + gs + images),
+                                  ("mg_reset, every environment", lambda: env.reset(layout_idx=idx), 2 * (hs + gs) + images)):
+            for _ in range(50):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(300):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) / 300 * 1e3
+            out.append(dict(workload=f"{name}, {agents} agents, {num_envs} envs", entry_point=entry, launch_us=us,
+                            algorithmic_bytes_per_env=nbytes, roofline_frac=num_envs * nbytes / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)))
+        env.close()
+    return out
+
+
 def memory_rates(dev):
     """What this GPU's memory system gives plain streaming kernels (tools/membench/copy_rate.hip: 16 bytes per lane,
     grid-stride): a device-to-device copy (bytes read + bytes written per second) and a fill (bytes written per
@@ -737,6 +779,7 @@ def main(argv=None):
                                                                "roofline_frac")}
                 line["stream_sharded"]["speedup_over_one_stream"] = twin["value"] / value
         line["config1_one_env"] = latency_one_env(args)
+        line["other_entry_points"] = other_entry_points(args)
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_leg(args.config)
         line["cpu_baseline"]["host_cpus"] = os.cpu_count()
