@@ -1,19 +1,32 @@
 """Long randomized parity run against the C oracle (test infrastructure, not a product path): many steps of mid-sized
 batches with same-step auto-reset, biased action mixes that make pickups, drops, door toggles and hook events frequent.
-    python tools/soak_parity.py [seconds per case]        (SOAK_SHARDS=2: through StreamShardedMultiGrid)"""
+    python tools/soak_parity.py [seconds per case]        (SOAK_SHARDS=2: through StreamShardedMultiGrid;
+                                                            SOAK_FUSED=T: T steps per launch through mg_step_n)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import test_gpu_batch as tb
+from multigrid_amd.batched import StepOutput
 
 SHARDS = int(os.environ.get("SOAK_SHARDS", "1"))
-CASES = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_nooverlap", "crowd8_bup", "crowd6_lh", "crowd8_rbd", "odd3", "odd5", "single", "lh8"]
+FUSED = int(os.environ.get("SOAK_FUSED", "1"))
+CASES = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5_nooverlap", "crowd8_bup", "crowd6_lh", "crowd8_rbd", "odd3", "odd5", "single", "lh8",
+         "view9_bup", "view11_lh", "view9_see", "view3_rbd", "view5_lh"]
+# the views other than 7 x 7 (the 9 x 9 and 11 x 11 ones run the kernel's general forms)
+TABLE = dict(tb.CASES)
+TABLE.update({
+    "view9_bup": ("MultiGrid-BlockedUnlockPickup-v0", 2, dict(max_steps=60, agent_view_size=9)),
+    "view11_lh": ("MultiGrid-LockedHallway-2Rooms-v0", 3, dict(max_steps=40, agent_view_size=11)),
+    "view9_see": ("MultiGrid-Empty-8x8-v0", 4, dict(max_steps=40, agent_view_size=9, see_through_walls=True)),
+    "view3_rbd": ("MultiGrid-RedBlueDoors-8x8-v0", 2, dict(max_steps=40, agent_view_size=3)),
+    "view5_lh": ("MultiGrid-LockedHallway-4Rooms-v0", 4, dict(max_steps=50, agent_view_size=5)),
+})
 MIXES = [None, [1, 1, 3, 2, 2, 3, 1], [1, 1, 2, 4, 1, 4, 0]]  # weights over left right forward pickup drop toggle done
 
 
 def run(case, seconds, e=3000, seed=0):
-    spec, pool, env, ora = tb.make(case, e, autoreset=2)
+    spec, pool, env, ora = tb.make(case, e, table=TABLE, autoreset=2)
     if SHARDS > 1:  # the same batch as slices on streams of their own (mg_step_shards)
         from multigrid_amd.sharded import StreamShardedMultiGrid
         env.close()
@@ -27,7 +40,7 @@ def run(case, seconds, e=3000, seed=0):
     idx = tb.expected_layout(ids_all, episode, n_l)
     ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
     t0, t, events = time.time(), 0, np.zeros(3, np.int64)
-    while time.time() - t0 < seconds:
+    while time.time() - t0 < seconds or t % FUSED:
         mix = MIXES[(t // 50) % len(MIXES)]
         if mix is None:
             actions = rng.integers(0, 7, size=(e, a)).astype(np.uint8)
@@ -35,7 +48,20 @@ def run(case, seconds, e=3000, seed=0):
             w = np.asarray(mix, float) / sum(mix)
             actions = rng.choice(7, size=(e, a), p=w).astype(np.uint8)
         order = np.argsort(rng.random(size=(e, a)), axis=-1).astype(np.uint8)
-        out = env.step(actions, order)
+        if FUSED > 1:
+            # T steps by one library call: this call draws the inputs of all of them, the oracle then takes them one by one
+            if t % FUSED == 0:
+                mixes = [MIXES[((t + k) // 50) % len(MIXES)] for k in range(FUSED)]
+                acts_n = np.stack([rng.integers(0, 7, size=(e, a)) if m is None else
+                                   rng.choice(7, size=(e, a), p=np.asarray(m, float) / sum(m)) for m in mixes]).astype(np.uint8)
+                order_n = np.argsort(rng.random(size=(FUSED, e, a)), axis=-1).astype(np.uint8)
+                out_n = env.step_n(acts_n, order_n)
+            k = t % FUSED
+            actions, order = acts_n[k], order_n[k]
+            out = StepOutput(*[None if x is None else x[k] for x in
+                                  (out_n.image, out_n.direction, out_n.reward, out_n.terminated, out_n.truncated)])
+        else:
+            out = env.step(actions, order)
         res = ora.step(actions, order)
         tb.compare(out, res, f"{case} step {t}")
         events += [int((res[2] != 0).sum()), int(res[3].sum()), int(res[4].all(axis=1).sum())]
@@ -45,7 +71,7 @@ def run(case, seconds, e=3000, seed=0):
             episode[ids] += 1
             idx = tb.expected_layout(ids, episode[ids], n_l)
             ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
-        if t % 200 == 0:
+        if (t + 1) % FUSED == 0 and (t // FUSED) % max(1, 200 // FUSED) == 0:  # (the device is T steps ahead inside a fused call)
             tb.compare_state(env, ora, f"{case} state at step {t}")
         t += 1
     tb.compare_state(env, ora, f"{case} final")
@@ -55,6 +81,8 @@ def run(case, seconds, e=3000, seed=0):
 
 if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+    only = [c for c in os.environ.get("SOAK_CASES", "").split(",") if c]  # a subset, by name
     for i, c in enumerate(CASES):
-        run(c, secs, seed=i)
+        if not only or c in only:
+            run(c, secs, seed=i)
     print("soak ok")
