@@ -79,10 +79,63 @@ def run(case, seconds, e=3000, seed=0):
     print(f"{case}: {t} steps x {e} envs bit-exact; rewards paid {events[0]}, terminations {events[1]}, truncated episodes {events[2]}", flush=True)
 
 
+COMP_CASES = {
+    "comp_1v1": ("DTDE-1v1", dict(max_steps=40)),
+    "comp_2v2_dm": ("DTDE-2v2-Death-Match", dict(max_steps=50)),
+    "comp_ctce_v3": ("CTCE-2v2", dict(max_steps=40, agent_view_size=3)),
+    "comp_ctde_all": ("CTDE-2v2", dict(max_steps=40, success_termination_mode="all", allow_agent_overlap=True, death_match=True)),
+    "comp_obstacle": ("DTDE-Red-Single-with-Obstacle", dict(max_steps=30)),
+}
+
+
+def run_comp(case, seconds, e=3000, seed=0):
+    """CompetativeRedBlueDoor environments: as run(), with the step's info bytes compared too; every 40 steps the agents of
+    half of the environments are moved next to each other, to the keys and in front of the doors, so that eliminations,
+    pickups and door openings keep happening."""
+    import test_gpu_competitive as tc
+    name, kw = COMP_CASES[case]
+    spec, pool, env, ora = tc.make(name, e, autoreset=2, **kw)
+    a, n_l = spec["num_agents"], len(pool[0])
+    rng = np.random.default_rng(seed)
+    ids_all = np.arange(e)
+    episode = np.zeros(e, np.int64)
+    env.reset()
+    idx = tb.expected_layout(ids_all, episode, n_l)
+    ora.load(ids_all, pool[0][idx], pool[1][idx], pool[2][idx])
+    t0, t, events = time.time(), 0, np.zeros(4, np.int64)
+    while time.time() - t0 < seconds:
+        if t % 40 == 0:
+            tc.crowd(ora, rng)
+            env.set_state(grid=ora.grid, agents=ora.agents)
+        actions = rng.choice(7, size=(e, a), p=tc.PICKY).astype(np.uint8)
+        order = np.argsort(rng.random((e, a)), axis=1).astype(np.uint8)
+        out = env.step(actions, order)
+        res = ora.step(actions, order)
+        tb.compare(out, res, f"{case} step {t}")
+        tb.compare_info(out, ora.info, f"{case} step {t}")
+        events += [int((res[2] > 0.6).sum()), int((res[2] < -0.5).sum()), int(res[3].sum()), int((ora.info >> 6 != 0).sum())]
+        done = res[3].all(axis=1) | res[4].all(axis=1)
+        if done.any():
+            ids = np.nonzero(done)[0]
+            episode[ids] += 1
+            idx = tb.expected_layout(ids, episode[ids], n_l)
+            ora.load(ids, pool[0][idx], pool[1][idx], pool[2][idx])
+        if t % 100 == 0:
+            tb.compare_state(env, ora, f"{case} state at step {t}")
+        t += 1
+    tb.compare_state(env, ora, f"{case} final")
+    env.close()
+    print(f"{case}: {t} steps x {e} envs bit-exact (info bytes too); doors opened for a win {events[0]}, eliminations "
+          f"{events[1]}, terminations {events[2]}, rewarded pickups {events[3]}", flush=True)
+
+
 if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
     only = [c for c in os.environ.get("SOAK_CASES", "").split(",") if c]  # a subset, by name
     for i, c in enumerate(CASES):
         if not only or c in only:
             run(c, secs, seed=i)
+    for i, c in enumerate(COMP_CASES):
+        if (not only or c in only) and SHARDS == 1 and FUSED == 1:
+            run_comp(c, secs, seed=100 + i)
     print("soak ok")
