@@ -714,6 +714,11 @@ def main():
                  action_p=BIASED)
 
     # the registry entry constructed with the reference's own defaults (agent_view_size 5, base.py:96)
+    # registered configurations seen through 9 x 9 and 11 x 11 views, from untouched resets (replayed by the facade from seeds)
+    record_group("seeded_view9_lockedhallway2",
+                 lambda: make_env(*_ck(cfg["MultiGrid-LockedHallway-2Rooms-v0"], 3), view=9), 3, 60, 57, action_p=BIASED)
+    record_group("seeded_view11_blockedunlockpickup",
+                 lambda: make_env(*_ck(cfg["MultiGrid-BlockedUnlockPickup-v0"], 2), view=11), 3, 60, 58, action_p=BIASED)
     record_group("default_empty8",
                  lambda: EmptyEnv(agents=2, teams=teams_for(2), policies_map={}, **cfg["MultiGrid-Empty-8x8-v0"][1]),
                  3, 40, 21)

@@ -16,6 +16,9 @@ CASES = [
     ("cfg5_empty16", "MultiGrid-Empty-16x16-v0", 8, 17, {}),
     # constructed with the reference's own defaults: 5 x 5 views (multigrid/base.py:96)
     ("default_empty8", "MultiGrid-Empty-8x8-v0", 2, 21, {"agent_view_size": None}),
+    # registered configurations through 9 x 9 and 11 x 11 views (the reference takes any odd size, base.py:96)
+    ("seeded_view9_lockedhallway2", "MultiGrid-LockedHallway-2Rooms-v0", 3, 57, {"agent_view_size": 9}),
+    ("seeded_view11_blockedunlockpickup", "MultiGrid-BlockedUnlockPickup-v0", 2, 58, {"agent_view_size": 11}),
     # eight rooms: more rooms than door colours (locked_hallway.py:150-151), played by the recording's planner
     ("solve_lockedhallway8", "MultiGrid-LockedHallway-6Rooms-v0", 2, 55, {"num_rooms": 8, "room_size": 4, "max_steps": 2000}),
 ]
