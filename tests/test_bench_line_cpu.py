@@ -28,7 +28,7 @@ def test_no_time_ratio_is_named_a_fraction():
 
 
 def test_last_committed_bench_line_passes_when_present():
-    """The newest profiles/r*_bench.json of this build's own rounds from round 3 on obeys the rule."""
+    """The bench lines kept under profiles/ since the rule exists (r03_bench*.json onwards) obey it."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench*.json"))):
         line = json.load(open(path))
