@@ -56,6 +56,10 @@ def run(case, seconds, e=3000, seed=0):
                                    rng.choice(7, size=(e, a), p=np.asarray(m, float) / sum(m)) for m in mixes]).astype(np.uint8)
                 order_n = np.argsort(rng.random(size=(FUSED, e, a)), axis=-1).astype(np.uint8)
                 out_n = env.step_n(acts_n, order_n)
+                if isinstance(out_n, list):  # stream shards: one output per slice, [T, E_k, ...] each
+                    import torch
+                    out_n = StepOutput(*[torch.cat([getattr(o, f) for o in out_n], dim=1) for f in
+                                         ("image", "direction", "reward", "terminated", "truncated")])
             k = t % FUSED
             actions, order = acts_n[k], order_n[k]
             out = StepOutput(*[None if x is None else x[k] for x in
